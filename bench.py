@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""bench.py - particle-steps/s of the SPH hot path on MI355X.
+
+A "step" is one pass of the hot path (cell sort -> exact kNN -> density / pressure-gradient /
+viscosity sums -> dt -> leapfrog) over the whole particle set, state resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--workload NAME]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU); see sph_code_amd/multigpu.py.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic bytes per particle-step, K = 40, int32 indices internally
+B_SEARCH = 24 + 4 * 40 + 8       # R pos, W idx, W h                       = 192
+B_STEP_CORE = 1248               # search + 3 passes + integrator
+
+
+def cpu_baseline(workload, n_cpu, k):
+    """The oracle (NumPy/SciPy restatement of the reference, oracle/sph_oracle.py) timed on this
+    box's host cores on a bounded sample of the same workload: one step at n_cpu particles."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    s = ics.WORKLOADS[workload](n_cpu)
+    t0 = time.perf_counter()
+    orc.step(s, n_neigh=k, eps=0.1, first=True, workers=1)      # eps=0.1: the reference's call
+    dt = time.perf_counter() - t0
+    return {"value": n_cpu / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 step of the %s workload at N=%d (NumPy/SciPy oracle, 1 thread, eps=0.1 cKDTree "
+                      "as the reference calls it); host has %d cores" % (workload, n_cpu, os.cpu_count()),
+            "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="particles per GPU")
+    ap.add_argument("--workload", default="polytrope")
+    ap.add_argument("--k", type=int, default=40)
+    ap.add_argument("--cpu-n", type=int, default=100_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        from sph_code_amd import multigpu
+        return multigpu.bench_main(args, rank, local_rank, world)
+
+    import torch
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libsphx has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    state = ics.WORKLOADS[args.workload](args.n)
+    sim = Simulation(state, n_neigh=args.k, device=local_rank)
+    sim.step(args.warmup)
+    sim.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.step(args.steps)                 # returns after the library's stream has drained
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = sim.stats()
+
+    ms_step = dt / args.steps * 1e3
+    value = args.n * args.steps / dt
+    ms_search = st["ms_search"] / max(st["steps"], 1)      # HIP events on the library's stream
+    achieved = B_SEARCH * args.n / (ms_search * 1e-3) / 1e9
+    out = {
+        "metric": "particle-steps/sec + achieved HBM GB/s, 10^6-particle 3D sphere, 1/2/4/8 GPUs",
+        "value": value, "unit": "particle-steps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
+                               (args.workload, args.n, args.k),
+                   "particles_per_gpu": args.n, "decomposition": "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "knn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_particle": B_SEARCH, "kernel_ms": ms_search},
+        "step_model": {"algorithmic_bytes_per_particle_step": B_STEP_CORE,
+                       "achieved_GBs": B_STEP_CORE * value / 1e9,
+                       "frac_of_hbm_peak": B_STEP_CORE * value / 1e9 / HBM_PEAK_GBS},
+        "per_pass_ms": {k_: st[k_] / max(st["steps"], 1) for k_ in
+                        ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi", "ms_visc",
+                         "ms_integrate", "ms_total")},
+        "search": {"candidates_per_particle_step": st["candidates"] / max(st["steps"], 1) / args.n,
+                   "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"]},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_n, args.k)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/* sphx.h - C ABI of libsphx.so: the MI355X (gfx950) implementation of the SPH inner
+ * loop of dmuley/sph-code.
+ *
+ * The reference has no FFI; its boundary for this path is the set of module-level
+ * Python callables of sph/navier_stokes_cleaned.py ("nsc") that the driver
+ * sph/code_running.py ("drv") invokes as nsc.<name>(...).  Each entry point below
+ * names the reference callable it replaces (file:line).  The Python side
+ * (sph_code_amd/compat.py) binds them with ctypes and keeps the reference's
+ * positional signatures and return tuples.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array is C-contiguous; "f64" = double.
+ *   - host-pointer entry points copy in, run on the context's HIP stream, copy out
+ *     and synchronise before returning; no pointer is retained after return.
+ *   - *_dev entry points take DEVICE pointers (memory owned by the caller, e.g. a
+ *     torch tensor's data_ptr()) and are asynchronous on the context's stream.
+ *   - return value: 0 = ok, < 0 = error (SPHX_E_*); sphx_last_error(ctx) gives text.
+ *   - one context per GPU per process; a context is not thread-safe; different
+ *     contexts may be used concurrently.
+ *   - missing neighbours are encoded as index == n (reference convention, nsc:545-548)
+ *     and contribute zero to every sum (the reference raises IndexError).
+ */
+#ifndef SPHX_H
+#define SPHX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHX_OK            0
+#define SPHX_E_ARG        -1   /* bad argument (null pointer, k > 64, n < 1 ...) */
+#define SPHX_E_HIP        -2   /* a HIP runtime call failed                      */
+#define SPHX_E_NOMEM      -3   /* device allocation failed                       */
+#define SPHX_E_STATE      -4   /* call sequence error (e.g. step before upload)  */
+
+#define SPHX_MAX_K        64   /* one neighbour per lane of a 64-wide wavefront  */
+#define SPHX_MAX_SPECIES  32
+
+typedef struct sphx_ctx sphx_ctx;
+
+/* Physical constants read by the path (nsc:21-52).  Defaults are the values the
+ * golden fixtures were generated with; sphx_set_constants overrides them. */
+typedef struct sphx_constants {
+    double k_B;      /* nsc:22  scipy.constants.Boltzmann                  */
+    double amu;      /* nsc:25  atomic mass constant                       */
+    double m_h;      /* nsc:29  1.0008 amu                                 */
+    double m_0;      /* nsc:36  10^1.5 solar masses                        */
+    double dt_0;     /* nsc:38  250000 yr                                  */
+    double max_age;  /* drv:79  3e7 yr                                     */
+    double pos_clamp;/* drv:233 1e11 AU                                    */
+} sphx_constants;
+
+/* Per-pass timing / traffic model of the last sphx_step call. */
+typedef struct sphx_stats {
+    double ms_grid;        /* bbox + cell hash + counting sort + state permute */
+    double ms_search;      /* kNN kernel                                        */
+    double ms_prep;        /* gather-record build                               */
+    double ms_density;     /* pass 1: rho, rho_dust, n, grad P                  */
+    double ms_pi;          /* pass 2: Pi_i + crossing time                      */
+    double ms_visc;        /* pass 3: viscous accel + heat                      */
+    double ms_integrate;   /* dt + leapfrog                                     */
+    double ms_total;       /* events around the whole step                      */
+    int64_t n;             /* particles                                         */
+    int64_t steps;         /* steps accumulated in the ms_* sums                */
+    int64_t candidates;    /* candidate distance evaluations in the search      */
+    int64_t retries;       /* searches repeated with a larger radius            */
+    int64_t cells;         /* cells of the last grid                            */
+    double  cell_size;     /* edge of the last grid's cells                     */
+} sphx_stats;
+
+/* ---- context ----------------------------------------------------------------------- */
+int         sphx_create(sphx_ctx** out, int device);
+void        sphx_destroy(sphx_ctx* ctx);
+const char* sphx_last_error(const sphx_ctx* ctx);
+int         sphx_version(void);
+int         sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c);
+int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
+
+/* ---- nsc.neighbors(points, dist, N_NEIGH)                          nsc:541-552 ----- *
+ * Exact k nearest neighbours (Euclidean) within `dist`; `eps` is accepted for API
+ * compatibility (the reference passes 0.1 to cKDTree) and ignored: the result is the
+ * eps = 0 answer, which satisfies every guarantee of the eps > 0 one.
+ *   points  (n,3) f64      idx      (n,k) int64, sorted by distance, column 0 = self,
+ *                                   missing = n
+ *   dist_out (n,k) f64 (missing = 0)   nontriv (n,) int64   h (n,) f64 = max distance  */
+int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* points, double dist,
+                   double eps, int64_t* idx, double* dist_out, int64_t* nontriv, double* h);
+
+/* ---- nsc.hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array,
+ *                       gamma_array, velocities)                     nsc:556-671 ----- *
+ * visc_mode 0 = "ref_axis0": Pi_i = sum_k pi_ik, the axis repair of nsc:649.
+ * Outputs keep the reference's sign (+grad P / rho) and layouts:
+ *   hydro_accel, visc_accel (n,3); visc_heat, rho, nden, rho_dust (n,); f_un_nb (s,n).
+ * Any output pointer may be NULL (that output is skipped).                              */
+int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const int64_t* neighbor,
+                      const double* points, const double* mass, const double* sizes,
+                      const double* f_un, const double* particle_type, const double* T,
+                      const double* mu_array, const double* gamma_array,
+                      const double* velocities, int visc_mode,
+                      double* hydro_accel, double* visc_accel, double* visc_heat,
+                      double* rho, double* nden, double* f_un_nb, double* rho_dust);
+
+/* ---- loop forms (h = (m/m_0)^(1/3) d, d = the driver-injected global nsc.d) ---------- */
+/* nsc.density(points,mass,particle_type,neighbor)                    nsc:693-702        */
+int sphx_density(sphx_ctx* ctx, int64_t n, int k, const double* points, const double* mass,
+                 const double* particle_type, const int64_t* neighbor, double d, double* out);
+/* nsc.dust_density(points,mass,neighbor,particle_type,sizes)         nsc:704-717        */
+int sphx_dust_density(sphx_ctx* ctx, int64_t n, int k, const double* points, const double* mass,
+                      const int64_t* neighbor, const double* particle_type, const double* sizes,
+                      double* out);
+/* nsc.num_dens(mass,points,mu_array,neighbor)                        nsc:744-753        */
+int sphx_num_dens(sphx_ctx* ctx, int64_t n, int k, const double* mass, const double* points,
+                  const double* mu_array, const int64_t* neighbor, double d, double* out);
+/* nsc.del_pressure(points,mass,particle_type,neighbor,E_internal,gamma_array) nsc:755-774 */
+int sphx_del_pressure(sphx_ctx* ctx, int64_t n, int k, const double* points, const double* mass,
+                      const double* particle_type, const int64_t* neighbor,
+                      const double* E_internal, const double* gamma_array, double d,
+                      double* out /* (n,3) */);
+/* nsc.artificial_viscosity(neighbor,points,particle_type,sizes,mass,densities,velocities,
+ *                          T,gamma_array,mu_array)                   nsc:788-816        */
+int sphx_artificial_viscosity(sphx_ctx* ctx, int64_t n, int k, const int64_t* neighbor,
+                              const double* points, const double* particle_type,
+                              const double* sizes, const double* mass, const double* densities,
+                              const double* velocities, const double* T,
+                              const double* gamma_array, const double* mu_array, double d,
+                              double* visc_accel /* (n,3) */, double* visc_heat /* (n,) */);
+/* nsc.crossing_time(neighbor,velocities,sizes,particle_type)         nsc:776-786        */
+int sphx_crossing_time(sphx_ctx* ctx, int64_t n, int k, const int64_t* neighbor,
+                       const double* velocities, const double* sizes,
+                       const double* particle_type, double* out /* scalar */);
+/* nsc.net_impulse(points,mass,sizes,velocities,particle_type,neighbor,f_un) nsc:719-742
+ * mean_grain_mass/mean_cross are the per-particle sums meff.f_un, seff.f_un (nsc:720-726),
+ * formed by the caller from nsc.grain_mass / nsc.sigma_effective.                        */
+int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* points, const double* mass,
+                     const double* sizes, const double* velocities, const double* particle_type,
+                     const int64_t* neighbor, const double* mean_grain_mass,
+                     const double* mean_cross, double* accel_onto /* (n,3) */,
+                     double* accel_reaction /* (n,3) */);
+
+/* ---- device-resident simulation state: the fused hot path of drv:217-491 ------------- *
+ * upload once, step many times (search -> dt -> sums -> leapfrog, nothing leaves HBM),
+ * download when needed.  Particle order on the device changes every step (cell sort);
+ * download returns arrays in the original order (by particle id).
+ *   pos, vel, accel_old (n,3); mass, ptype, T, mu, gamma, E (n,); f_un (n,s) or NULL.   */
+int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const double* vel,
+                      const double* mass, const double* ptype, const double* f_un,
+                      const double* T, const double* mu, const double* gamma,
+                      const double* E_internal, const double* accel_old);
+/* One or more passes of the hot path.  k = N_NEIGH, dist = distance_upper_bound of
+ * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);
+ * fixed_dt > 0 overrides the crossing-time rule (drv:225-229).                           */
+int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int first, double fixed_dt);
+int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, double* accel,
+                        double* E_internal, double* T, double* sizes, double* rho,
+                        double* nden, double* visc_heat, double* dt_last);
+int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out);
+int sphx_reset_stats(sphx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_H */

@@ -1,0 +1,165 @@
+"""ctypes binding of libsphx.so (C ABI: include/sphx.h).  No CPU fallback."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsphx.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class SphxConstants(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("k_B", "amu", "m_h", "m_0", "dt_0", "max_age", "pos_clamp")]
+
+
+class SphxStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi",
+                                          "ms_visc", "ms_integrate", "ms_total")] + \
+               [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells")] + \
+               [("cell_size", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/sphx.h declares
+_P = C.c_void_p
+_D = c_double_p
+_I = c_int64_p
+SIGNATURES = {
+    "sphx_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "sphx_destroy": (None, [_P]),
+    "sphx_last_error": (C.c_char_p, [_P]),
+    "sphx_version": (C.c_int, []),
+    "sphx_set_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
+    "sphx_get_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
+    "sphx_neighbors": (C.c_int, [_P, C.c_int64, C.c_int, _D, C.c_double, C.c_double, _I, _D, _I, _D]),
+    "sphx_hydro_update": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _I] + [_D] * 9 + [C.c_int] + [_D] * 7),
+    "sphx_density": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _I, C.c_double, _D]),
+    "sphx_dust_density": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _I, _D, _D, _D]),
+    "sphx_num_dens": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _I, C.c_double, _D]),
+    "sphx_del_pressure": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _I, _D, _D, C.c_double, _D]),
+    "sphx_artificial_viscosity": (C.c_int, [_P, C.c_int64, C.c_int, _I] + [_D] * 9 + [C.c_double, _D, _D]),
+    "sphx_crossing_time": (C.c_int, [_P, C.c_int64, C.c_int, _I, _D, _D, _D, _D]),
+    "sphx_net_impulse": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _D, _D, _I, _D, _D, _D, _D]),
+    "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
+    "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),
+    "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
+    "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),
+    "sphx_reset_stats": (C.c_int, [_P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libsphx.so and attach prototypes.  Raises if the library is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libsphx.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python sph-code_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def f64(a, shape=None):
+    """C-contiguous float64 view/copy (mass and f_un arrive as longdouble from the driver,
+    sph/code_running.py:152-154: cast, as nsc:559-565 does for the other arrays)."""
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and out.shape != shape:
+        raise ValueError("expected shape %s, got %s" % (shape, out.shape))
+    return out
+
+
+def i64(a, shape=None):
+    out = np.ascontiguousarray(a, dtype=np.int64)
+    if shape is not None and out.shape != shape:
+        raise ValueError("expected shape %s, got %s" % (shape, out.shape))
+    return out
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def ip(a):
+    return None if a is None else a.ctypes.data_as(c_int64_p)
+
+
+class Context:
+    """One libsphx context = one GPU + one HIP stream.  Not thread-safe."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        h = C.c_void_p()
+        rc = self.lib.sphx_create(C.byref(h), device)
+        if rc != 0 or not h:
+            raise RuntimeError("sphx_create(device=%d) failed with %d: no usable MI355X/HIP device "
+                               "(libsphx has no CPU path)" % (device, rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sphx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.sphx_last_error(self.h)
+        msg = msg.decode() if msg else ""
+        if rc == -1:
+            raise ValueError("libsphx: " + msg)
+        raise RuntimeError("libsphx error %d: %s" % (rc, msg))
+
+    def constants(self):
+        c = SphxConstants()
+        self.check(self.lib.sphx_get_constants(self.h, C.byref(c)))
+        return c
+
+    def set_constants(self, **kw):
+        c = self.constants()
+        for k_, v in kw.items():
+            setattr(c, k_, v)
+        self.check(self.lib.sphx_set_constants(self.h, C.byref(c)))
+
+    def stats(self):
+        s = SphxStats()
+        self.check(self.lib.sphx_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self.check(self.lib.sphx_reset_stats(self.h))
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default

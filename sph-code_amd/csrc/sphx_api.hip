@@ -1,0 +1,425 @@
+// sphx_api.hip - the C ABI of include/sphx.h: context, host-pointer entry points that mirror
+// the reference's Python callables, and the device-resident step loop.
+#include "sphx_internal.h"
+#include <stdarg.h>
+#include <new>
+
+int sphx_set_err(sphx_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int sphx_ensure(sphx_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (b.cap >= bytes) return SPHX_OK;
+    if (b.p) {
+        // buffers may still be referenced by queued work
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return sphx_set_err(ctx, SPHX_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return SPHX_OK;
+}
+
+static void default_constants(sphx_constants* c) {
+    c->k_B = 1.380649e-23;
+    c->amu = 1.66053906892e-27;
+    c->m_h = 1.0008 * c->amu;
+    c->m_0 = 31.622776601683793 * 1.989e30;          // 10**1.5 * solar_mass, nsc:36
+    c->dt_0 = 60. * 60. * 24. * 365. * 250000.;
+    c->max_age = 3e7 * 60. * 60. * 24. * 365.;
+    c->pos_clamp = 1e11 * 149597870700.0;
+}
+
+extern "C" int sphx_version(void) { return 100; }
+
+extern "C" int sphx_create(sphx_ctx** out, int device) {
+    if (!out) return SPHX_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        fprintf(stderr, "sphx_create: no usable HIP device %d (found %d). libsphx has no CPU path.\n",
+                device, count);
+        return SPHX_E_HIP;
+    }
+    sphx_ctx* ctx = new (std::nothrow) sphx_ctx();
+    if (!ctx) return SPHX_E_NOMEM;
+    ctx->device = device;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    memset(&ctx->grid, 0, sizeof(ctx->grid));
+    default_constants(&ctx->cst);
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    if (ok) ok = sphx_ensure(ctx, ctx->scal, SC_NSLOTS * 8) == SPHX_OK &&
+                 hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "sphx_create: HIP initialisation failed on device %d\n", device);
+        delete ctx;
+        return SPHX_E_HIP;
+    }
+    *out = ctx;
+    return SPHX_OK;
+}
+
+static void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+static void free_state(StateArrays& s) {
+    DevBuf* all[] = {&s.x, &s.y, &s.z, &s.vx, &s.vy, &s.vz, &s.ax, &s.ay, &s.az, &s.m, &s.T,
+                     &s.mu, &s.gam, &s.E, &s.hprev, &s.ptype, &s.id, &s.fun};
+    for (DevBuf* b : all) free_buf(*b);
+}
+
+extern "C" void sphx_destroy(sphx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
+                     &ctx->Pi, &ctx->Bw, &ctx->csi, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F, &ctx->relv,
+                     &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
+                     &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
+                     &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
+                     &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
+                     &ctx->nontriv, &ctx->h_api};
+    for (DevBuf* b : all) free_buf(*b);
+    free_state(ctx->st);
+    free_state(ctx->alt);
+    for (int i = 0; i < 10; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* sphx_last_error(const sphx_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c) {
+    if (!ctx || !c) return SPHX_E_ARG;
+    ctx->cst = *c;
+    return SPHX_OK;
+}
+extern "C" int sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c) {
+    if (!ctx || !c) return SPHX_E_ARG;
+    *c = ctx->cst;
+    return SPHX_OK;
+}
+
+// ---- staging helpers ------------------------------------------------------------------------
+static int upload(sphx_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
+    SPHX_TRY(sphx_ensure(ctx, b, bytes));
+    HIPCHK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SPHX_OK;
+}
+static int download(sphx_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    if (!host) return SPHX_OK;
+    HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return SPHX_OK;
+}
+#define NEED(p)                                                                              \
+    do {                                                                                     \
+        if (!(p)) return sphx_set_err(ctx, SPHX_E_ARG, "%s: argument %s is NULL", __func__, #p); \
+    } while (0)
+
+// =============================================================================================
+// nsc.neighbors                                                                nsc:541-552
+// =============================================================================================
+extern "C" int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* points, double dist,
+                              double eps, int64_t* idx, double* dist_out, int64_t* nontriv,
+                              double* h) {
+    (void)eps;
+    if (!ctx) return SPHX_E_ARG;
+    NEED(points);
+    if (n < 1) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld < 1", (long long)n);
+    if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * sizeof(double);
+    SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_b, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_c, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_d, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_e, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_f, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->in_g, nb));
+    double *x = ctx->in_b.as<double>(), *y = ctx->in_c.as<double>(), *z = ctx->in_d.as<double>();
+    double *xs = ctx->in_e.as<double>(), *ys = ctx->in_f.as<double>(), *zs = ctx->in_g.as<double>();
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, ctx->in_a.as<double>(), x, y, z));
+    SPHX_TRY(sphx_build_grid(ctx, n, k, x, y, z, 0.0));
+    SPHX_TRY(sphx_gather3(ctx, n, ctx->perm.as<int>(), x, y, z, xs, ys, zs));
+    SPHX_TRY(sphx_ensure(ctx, ctx->idx64, (size_t)n * k * sizeof(int64_t)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->dist_out, (size_t)n * k * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->nontriv, (size_t)n * sizeof(int64_t)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->h_api, nb));
+    KnnOut o;
+    o.nbr = nullptr; o.h_sorted = nullptr;
+    o.idx64 = ctx->idx64.as<int64_t>(); o.dist = ctx->dist_out.as<double>();
+    o.nontriv = ctx->nontriv.as<int64_t>(); o.h_by_id = ctx->h_api.as<double>();
+    // sorted -> original index is the permutation itself
+    SPHX_TRY(sphx_knn(ctx, n, k, xs, ys, zs, ctx->perm.as<int>(), nullptr, nullptr, 1.0, dist, o));
+    SPHX_TRY(download(ctx, idx, o.idx64, (size_t)n * k * sizeof(int64_t)));
+    SPHX_TRY(download(ctx, dist_out, o.dist, (size_t)n * k * sizeof(double)));
+    SPHX_TRY(download(ctx, nontriv, o.nontriv, (size_t)n * sizeof(int64_t)));
+    SPHX_TRY(download(ctx, h, o.h_by_id, nb));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}
+
+// =============================================================================================
+// nsc.hydro_update                                                             nsc:556-671
+// =============================================================================================
+extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const int64_t* neighbor,
+                                 const double* points, const double* mass, const double* sizes,
+                                 const double* f_un, const double* particle_type, const double* T,
+                                 const double* mu_array, const double* gamma_array,
+                                 const double* velocities, int visc_mode, double* hydro_accel,
+                                 double* visc_accel, double* visc_heat, double* rho, double* nden,
+                                 double* f_un_nb, double* rho_dust) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(neighbor); NEED(points); NEED(mass); NEED(sizes); NEED(particle_type); NEED(T);
+    NEED(mu_array); NEED(gamma_array); NEED(velocities);
+    if (n < 1 || n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
+    if (k < 1 || k > 4096) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d out of range", k);
+    if (visc_mode != 0) return sphx_set_err(ctx, SPHX_E_ARG, "visc_mode %d unknown (0 = ref_axis0)", visc_mode);
+    if (f_un_nb && (!f_un || s < 1 || s > SPHX_MAX_SPECIES))
+        return sphx_set_err(ctx, SPHX_E_ARG, "species output needs f_un and 1 <= s <= %d", SPHX_MAX_SPECIES);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * sizeof(double);
+    SPHX_TRY(upload(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
+    SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
+    SPHX_TRY(upload(ctx, ctx->in_b, velocities, 3 * nb));
+    SPHX_TRY(upload(ctx, ctx->in_c, mass, nb));
+    SPHX_TRY(upload(ctx, ctx->in_d, sizes, nb));
+    SPHX_TRY(upload(ctx, ctx->in_e, T, nb));
+    SPHX_TRY(upload(ctx, ctx->in_f, mu_array, nb));
+    SPHX_TRY(upload(ctx, ctx->in_g, gamma_array, nb));
+    SPHX_TRY(upload(ctx, ctx->in_h, particle_type, nb));
+    SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
+    SPHX_TRY(sphx_prep(ctx, n, nullptr, nullptr, nullptr, ctx->in_a.as<double>(), nullptr, nullptr,
+                       nullptr, ctx->in_b.as<double>(), ctx->in_c.as<double>(), ctx->in_d.as<double>(),
+                       ctx->in_e.as<double>(), ctx->in_f.as<double>(), ctx->in_g.as<double>(),
+                       ctx->in_h.as<double>()));
+    SPHX_TRY(sphx_pass_density(ctx, n, k));
+    SPHX_TRY(sphx_pass_pi(ctx, n, k, ctx->in_d.as<double>(), ctx->in_h.as<double>()));
+    SPHX_TRY(sphx_pass_visc(ctx, n, k, ctx->in_c.as<double>()));
+    if (f_un_nb) {
+        SPHX_TRY(upload(ctx, ctx->in_i, f_un, (size_t)n * s * sizeof(double)));
+        SPHX_TRY(sphx_ensure(ctx, ctx->F, (size_t)n * s * sizeof(double)));
+        SPHX_TRY(sphx_pass_species(ctx, n, k, s, ctx->in_i.as<double>(), ctx->F.as<double>()));
+        SPHX_TRY(download(ctx, f_un_nb, ctx->F.p, (size_t)n * s * sizeof(double)));
+    }
+    SPHX_TRY(download(ctx, hydro_accel, ctx->ha.p, 3 * nb));
+    SPHX_TRY(download(ctx, visc_accel, ctx->va.p, 3 * nb));
+    SPHX_TRY(download(ctx, visc_heat, ctx->vh.p, nb));
+    SPHX_TRY(download(ctx, rho, ctx->rho.p, nb));
+    SPHX_TRY(download(ctx, nden, ctx->nden.p, nb));
+    SPHX_TRY(download(ctx, rho_dust, ctx->rhod.p, nb));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}
+
+// =============================================================================================
+// device-resident state + step                                       drv:217-238, 437-491
+// =============================================================================================
+extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const double* vel,
+                                 const double* mass, const double* ptype, const double* f_un,
+                                 const double* T, const double* mu, const double* gamma,
+                                 const double* E_internal, const double* accel_old) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel); NEED(mass); NEED(ptype); NEED(T); NEED(mu); NEED(gamma); NEED(E_internal);
+    if (n < 1 || n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
+    if (f_un && (s < 1 || s > SPHX_MAX_SPECIES)) return sphx_set_err(ctx, SPHX_E_ARG, "s=%d out of range", s);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * sizeof(double);
+    StateArrays& st = ctx->st;
+    DevBuf* scal[] = {&st.x, &st.y, &st.z, &st.vx, &st.vy, &st.vz, &st.ax, &st.ay, &st.az,
+                      &st.m, &st.T, &st.mu, &st.gam, &st.E, &st.hprev, &st.ptype};
+    for (DevBuf* b : scal) SPHX_TRY(sphx_ensure(ctx, *b, nb));
+    SPHX_TRY(sphx_ensure(ctx, st.id, (size_t)n * sizeof(int)));
+    SPHX_TRY(upload(ctx, ctx->in_a, pos, 3 * nb));
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, ctx->in_a.as<double>(), st.x.as<double>(), st.y.as<double>(), st.z.as<double>()));
+    SPHX_TRY(upload(ctx, ctx->in_b, vel, 3 * nb));
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, ctx->in_b.as<double>(), st.vx.as<double>(), st.vy.as<double>(), st.vz.as<double>()));
+    if (accel_old) {
+        SPHX_TRY(upload(ctx, ctx->in_c, accel_old, 3 * nb));
+        SPHX_TRY(sphx_aos_to_soa3(ctx, n, ctx->in_c.as<double>(), st.ax.as<double>(), st.ay.as<double>(), st.az.as<double>()));
+    } else {
+        HIPCHK(hipMemsetAsync(st.ax.p, 0, nb, ctx->stream));
+        HIPCHK(hipMemsetAsync(st.ay.p, 0, nb, ctx->stream));
+        HIPCHK(hipMemsetAsync(st.az.p, 0, nb, ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(st.m.p, mass, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(st.T.p, T, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(st.mu.p, mu, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(st.gam.p, gamma, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(st.E.p, E_internal, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(st.ptype.p, ptype, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(st.hprev.p, 0, nb, ctx->stream));
+    SPHX_TRY(sphx_iota(ctx, n, st.id.as<int>()));
+    ctx->s = 0;
+    if (f_un) {
+        SPHX_TRY(upload(ctx, st.fun, f_un, (size_t)n * s * sizeof(double)));
+        ctx->s = s;
+    }
+    HIPCHK(hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->n = n;
+    ctx->npad = sphx_pad64(n);
+    ctx->has_state = true;
+    ctx->step_count = 0;
+    ctx->dt_last = 0.0;
+    return SPHX_OK;
+}
+
+static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_dt) {
+    const int64_t n = ctx->n;
+    hipEvent_t* ev = ctx->ev;
+    HIPCHK(hipEventRecord(ev[0], ctx->stream));
+    // drv:233-238
+    SPHX_TRY(sphx_clamp(ctx, n, ctx->st));
+    // cell size from the previous step's mean h (read back together with the bounding box)
+    double cell_hint = 0.0;
+    if (ctx->step_count > 0) {
+        HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    }
+    {
+        StateArrays& s = ctx->st;
+        // sphx_build_grid synchronises the stream (bounding-box read-back)
+        if (ctx->step_count > 0) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            double hmean = *(double*)((char*)ctx->pinned + 256) / (double)n;
+            if (hmean > 0.0 && isfinite(hmean)) cell_hint = 0.6 * hmean;
+        }
+        SPHX_TRY(sphx_build_grid(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), cell_hint));
+    }
+    SPHX_TRY(sphx_permute_state(ctx, n));
+    HIPCHK(hipEventRecord(ev[1], ctx->stream));
+    StateArrays& s = ctx->st;
+    SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * ctx->npad * sizeof(int)));
+    KnnOut o;
+    o.nbr = ctx->nbr.as<int>();
+    o.h_sorted = s.hprev.as<double>();       // read as the search-radius hint, then overwritten
+    o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr; o.h_by_id = nullptr;
+    SPHX_TRY(sphx_knn(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), s.id.as<int>(),
+                      ctx->inv.as<int>(), s.hprev.as<double>(), 1.2, dist, o));
+    HIPCHK(hipEventRecord(ev[2], ctx->stream));
+    SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
+    SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
+                       s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
+                       s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
+                       s.ptype.as<double>()));
+    HIPCHK(hipEventRecord(ev[3], ctx->stream));
+    SPHX_TRY(sphx_pass_density(ctx, n, k));
+    HIPCHK(hipEventRecord(ev[4], ctx->stream));
+    SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
+    HIPCHK(hipEventRecord(ev[5], ctx->stream));
+    SPHX_TRY(sphx_pass_visc(ctx, n, k, s.m.as<double>()));
+    HIPCHK(hipEventRecord(ev[6], ctx->stream));
+    SPHX_TRY(sphx_compute_dt(ctx, first, fixed_dt));
+    SPHX_TRY(sphx_integrate(ctx, n));
+    HIPCHK(hipEventRecord(ev[7], ctx->stream));
+    ctx->step_count++;
+    return SPHX_OK;
+}
+
+static int collect_stats(sphx_ctx* ctx) {
+    hipEvent_t* ev = ctx->ev;
+    HIPCHK(hipEventSynchronize(ev[7]));
+    float ms[7];
+    for (int i = 0; i < 7; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    float tot;
+    HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[7]));
+    sphx_stats& st = ctx->stats;
+    st.ms_grid += ms[0]; st.ms_search += ms[1]; st.ms_prep += ms[2]; st.ms_density += ms[3];
+    st.ms_pi += ms[4]; st.ms_visc += ms[5]; st.ms_integrate += ms[6]; st.ms_total += tot;
+    st.steps += 1;
+    st.n = ctx->n;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int first, double fixed_dt) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_step before sphx_state_upload");
+    if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
+    if (nsteps < 1) return sphx_set_err(ctx, SPHX_E_ARG, "nsteps=%d < 1", nsteps);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!(dist > 0.0) || !isfinite(dist)) dist = 0.0;
+    ctx->k = k;
+    for (int it = 0; it < nsteps; ++it) {
+        SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt));
+        SPHX_TRY(collect_stats(ctx));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->scal.p, SC_NSLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const u64* sc = (const u64*)ctx->pinned;
+    ctx->dt_last = ((const double*)ctx->pinned)[SC_DT];
+    ctx->stats.candidates = (int64_t)sc[SC_CAND];
+    ctx->stats.retries = (int64_t)sc[SC_RETRY];
+    return SPHX_OK;
+}
+
+extern "C" int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, double* accel,
+                                   double* E_internal, double* T, double* sizes, double* rho,
+                                   double* nden, double* visc_heat, double* dt_last) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "no state uploaded");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const size_t nb = (size_t)n * sizeof(double);
+    StateArrays& s = ctx->st;
+    const int* id = s.id.as<int>();
+    SPHX_TRY(sphx_ensure(ctx, ctx->out_a, 3 * nb));
+    double* stage = ctx->out_a.as<double>();
+    struct V3 { double* host; DevBuf *a, *b, *c; };
+    V3 v3[] = {{pos, &s.x, &s.y, &s.z}, {vel, &s.vx, &s.vy, &s.vz}, {accel, &s.ax, &s.ay, &s.az}};
+    for (V3& v : v3) {
+        if (!v.host) continue;
+        SPHX_TRY(sphx_soa3_to_aos_by_id(ctx, n, id, v.a->as<double>(), v.b->as<double>(), v.c->as<double>(), stage));
+        SPHX_TRY(download(ctx, v.host, stage, 3 * nb));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    struct V1 { double* host; const double* dev; };
+    const bool stepped = ctx->step_count > 0;
+    V1 v1[] = {{E_internal, s.E.as<double>()}, {T, s.T.as<double>()}, {sizes, s.hprev.as<double>()},
+               {rho, stepped ? ctx->rho.as<double>() : nullptr},
+               {nden, stepped ? ctx->nden.as<double>() : nullptr},
+               {visc_heat, stepped ? ctx->vh.as<double>() : nullptr}};
+    for (V1& v : v1) {
+        if (!v.host) continue;
+        if (!v.dev) { memset(v.host, 0, nb); continue; }
+        SPHX_TRY(sphx_scatter_rows_by_id(ctx, n, 1, id, v.dev, stage));
+        SPHX_TRY(download(ctx, v.host, stage, nb));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (dt_last) *dt_last = ctx->dt_last;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
+    if (!ctx || !out) return SPHX_E_ARG;
+    *out = ctx->stats;
+    return SPHX_OK;
+}
+extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
+    if (!ctx) return SPHX_E_ARG;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_CAND, 0, 2 * sizeof(u64), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}

@@ -1,0 +1,234 @@
+// sphx_grid.hip - spatial hash: bounding box, cell ids, counting sort (cell list in HBM).
+//
+// Cell index is x-fastest: cell = (cz*ny + cy)*nx + cx, so a run of cells along x at fixed
+// (cy,cz) is one contiguous range of the sorted particle arrays (what sphx_knn.hip streams).
+// Coordinates outside the box are clamped into the boundary cells by the same monotone map
+// the search uses for its range ends, so clamping never loses a neighbour.
+#include "sphx_internal.h"
+
+#define RED_BLOCK 256
+#define RED_MAXBLOCKS 1024
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// partial[block][6] = {xmin,ymin,zmin,xmax,ymax,zmax}; NaN coordinates are ignored (fmin/fmax)
+__global__ __launch_bounds__(RED_BLOCK) void bbox_partial(int n, const double* x, const double* y,
+                                                          const double* z, double* partial) {
+    __shared__ double sm[RED_BLOCK / 64][6];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (isfinite(v[c])) { mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]); }
+        }
+    }
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) { sm[wave][c] = mn[c]; sm[wave][3 + c] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sm[0][threadIdx.x];
+        for (int w = 1; w < RED_BLOCK / 64; ++w)
+            v = threadIdx.x < 3 ? fmin(v, sm[w][threadIdx.x]) : fmax(v, sm[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void bbox_final(int nblocks, const double* partial, double* out) {
+    int c = threadIdx.x;
+    if (c < 6) {
+        double v = partial[c];
+        for (int b = 1; b < nblocks; ++b) v = c < 3 ? fmin(v, partial[b * 6 + c]) : fmax(v, partial[b * 6 + c]);
+        out[c] = v;
+    }
+}
+
+int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
+              double out_minmax[6]) {
+    int blocks = (int)((n + RED_BLOCK - 1) / RED_BLOCK);
+    if (blocks > RED_MAXBLOCKS) blocks = RED_MAXBLOCKS;
+    SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 1) * 6 * sizeof(double)));
+    double* part = ctx->bbox_tmp.as<double>();
+    double* fin = part + (size_t)RED_MAXBLOCKS * 6;
+    hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, part);
+    hipLaunchKernelGGL(bbox_final, dim3(1), dim3(64), 0, ctx->stream, blocks, part, fin);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ctx->pinned, fin, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(out_minmax, ctx->pinned, 6 * sizeof(double));
+    return SPHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_coord_g(double v, double vmin, double inv_cell, int nmax1) {
+    double t = (v - vmin) * inv_cell;
+    t = fmin(fmax(t, 0.0), (double)nmax1);
+    return (int)t;
+}
+
+__global__ __launch_bounds__(256) void cell_count(int n, const double* x, const double* y,
+                                                  const double* z, GridParams g, int* cell_of,
+                                                  int* hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cx = cell_coord_g(x[i], g.xmin, g.inv_cell, g.nx - 1);
+    int cy = cell_coord_g(y[i], g.ymin, g.inv_cell, g.ny - 1);
+    int cz = cell_coord_g(z[i], g.zmin, g.inv_cell, g.nz - 1);
+    int c = (cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+    atomicAdd(&hist[c], 1);
+}
+
+// three-phase exclusive scan of int32: 2048 items per block
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total_out) {
+    // returns exclusive prefix of v across the 256-thread block; *total_out = block total
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        int s = wsum[w];
+        if (w < wave) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total_out = tot;
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase1(int n, const int* in, int* block_sums) {
+    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) s += (base + q < n) ? in[base + q] : 0;
+    int tot;
+    block_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+// single block: exclusive scan of up to 4096 block sums, in place
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase2(int nb, int* block_sums, int* grand_total) {
+    int carry = 0;
+    for (int base = 0; base < nb; base += SCAN_BLOCK) {
+        int i = base + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int tot;
+        int ex = block_exclusive_scan(v, &tot);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+// out[i] = exclusive prefix; also out[n] = total (written by the last block)
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int n, const int* in, const int* block_sums,
+                                                          int* out) {
+    int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+        if (base + q < n) out[base + q] = ex;
+        ex += v[q];
+        if (base + q == n - 1) out[n] = ex;
+    }
+}
+
+__global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, const int* cell_start,
+                                                    int* fill, int* perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = cell_of[i];
+    int slot = cell_start[c] + atomicAdd(&fill[c], 1);
+    perm[slot] = i;
+}
+
+#define SPHX_MAX_CELLS (SCAN_TILE * 4096)
+
+int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
+                    const double* z, double cell_hint) {
+    double bb[6];
+    SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb));
+    for (int c = 0; c < 3; ++c) {
+        if (!(bb[3 + c] >= bb[c])) { bb[c] = 0.0; bb[3 + c] = 0.0; }   // no finite coordinate
+    }
+    double L[3];
+    double Lmax = 0.0;
+    for (int c = 0; c < 3; ++c) { L[c] = bb[3 + c] - bb[c]; if (L[c] > Lmax) Lmax = L[c]; }
+    if (!(Lmax > 0.0)) Lmax = 1.0;
+    double cell = cell_hint;
+    if (!(cell > 0.0) || !isfinite(cell)) {
+        // mean kNN radius of a uniform fill of the box, times 0.6
+        double V = 1.0;
+        for (int c = 0; c < 3; ++c) V *= (L[c] > 1e-6 * Lmax ? L[c] : 1e-6 * Lmax);
+        cell = 0.6 * cbrt(V * (double)k / ((double)n * 4.1887902047863905));
+    }
+    if (cell < Lmax * 1e-4) cell = Lmax * 1e-4;
+    int64_t cap = 8 * n + 1024;
+    if (cap > SPHX_MAX_CELLS) cap = SPHX_MAX_CELLS;
+    int nx, ny, nz;
+    for (;;) {
+        nx = (int)fmin(floor(L[0] / cell) + 1.0, 2047.0);
+        ny = (int)fmin(floor(L[1] / cell) + 1.0, 2047.0);
+        nz = (int)fmin(floor(L[2] / cell) + 1.0, 2047.0);
+        int64_t tot = (int64_t)nx * ny * nz;
+        if (tot <= cap) break;
+        cell *= 1.02 * cbrt((double)tot / (double)cap);
+    }
+    GridParams& g = ctx->grid;
+    g.xmin = bb[0]; g.ymin = bb[1]; g.zmin = bb[2];
+    g.cell = cell; g.inv_cell = 1.0 / cell;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    g.ncells = nx * ny * nz;
+    ctx->stats.cells = g.ncells;
+    ctx->stats.cell_size = cell;
+
+    const int nc = g.ncells;
+    SPHX_TRY(sphx_ensure(ctx, ctx->cell_of, (size_t)n * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->perm, (size_t)n * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->cell_start, ((size_t)nc + 2) * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->cell_fill, ((size_t)nc + 2) * sizeof(int)));
+    int nblk = (nc + SCAN_TILE - 1) / SCAN_TILE;
+    SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, ((size_t)nblk + 2) * sizeof(int)));
+    int* fill = ctx->cell_fill.as<int>();
+    int* start = ctx->cell_start.as<int>();
+    int* bsum = ctx->scan_tmp.as<int>();
+    HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));
+    int pb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
+                       ctx->cell_of.as<int>(), fill);
+    hipLaunchKernelGGL(scan_phase1, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum);
+    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, nblk, bsum, bsum + nblk);
+    hipLaunchKernelGGL(scan_phase3, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum, start);
+    HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
+                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>());
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

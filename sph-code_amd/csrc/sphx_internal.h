@@ -1,0 +1,156 @@
+// sphx_internal.h - shared declarations of libsphx (gfx950 only; no host fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/sphx.h"
+
+#define SPHX_WAVE 64
+#define SPHX_W6_C 1.5666814710608448    /* 315 / (64 pi), nsc:588 */
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------------------------------
+// device buffer with grow-only capacity
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Gather record of one particle (64 B, one half cache line): everything a neighbour
+// contributes to pass 1, so a neighbour costs one contiguous 64-B read.
+struct __attribute__((aligned(64))) Rec1 {
+    double x, y, z;   // position
+    double h2;        // h_j^2
+    double c1;        // 315 / (64 pi h_j^9)                             nsc:588
+    double ms;        // +m (gas), -m (dust), 0 (star): m*[t==0], m*[t==2] nsc:605-606
+    double A;         // m/mu/amu*k*T*[t==0]   pressure weight            nsc:615
+    double Nw;        // m/mu/amu*[t==0]       number weight              nsc:607,626
+};
+// velocity record for the viscosity passes
+struct __attribute__((aligned(32))) RecV {
+    double vx, vy, vz;
+    double cs;        // sqrt(gamma k T/mu/amu [t==0])                    nsc:647
+};
+
+struct GridParams {
+    double xmin, ymin, zmin;
+    double cell, inv_cell;
+    int nx, ny, nz;
+    int ncells;
+};
+
+// device-resident particle state, structure of arrays (one set; `alt` is the permute target)
+struct StateArrays {
+    DevBuf x, y, z, vx, vy, vz, ax, ay, az;      // position, velocity, previous total accel
+    DevBuf m, T, mu, gam, E, hprev;              // per-particle scalars
+    DevBuf ptype;                                // f64 0/1/2 as in the reference (drv:127)
+    DevBuf id;                                   // int32 persistent particle id
+    DevBuf fun;                                  // (n,s) f64 composition (optional)
+};
+
+struct sphx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    sphx_constants cst;
+    sphx_stats stats;
+
+    // ---- working set (any particle order) ----
+    int64_t n = 0, npad = 0;
+    int k = 0, s = 0;
+    DevBuf rec1, recv;            // Rec1[n], RecV[n]
+    DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
+    DevBuf rho, rhod, nden, G, Pi, Bw, csi, va, vh, ha, F;
+    DevBuf relv;                  // per-particle max relative speed^2 (crossing time)
+    DevBuf scal;                  // small device scalars: ct bits, dt, counters
+    // ---- grid ----
+    GridParams grid;
+    DevBuf cell_of, cell_start, cell_fill, perm, inv, scan_tmp, bbox_tmp;
+    // ---- host-API staging ----
+    DevBuf in_a, in_b, in_c, in_d, in_e, in_f, in_g, in_h, in_i, in_j, out_a, out_b, out_c;
+    DevBuf idx64, dist_out, nontriv, h_api;
+    // ---- simulation state ----
+    StateArrays st, alt;
+    bool has_state = false;
+    int64_t step_count = 0;
+    double dt_last = 0.0;
+    hipEvent_t ev[10] = {nullptr};
+    void* pinned = nullptr;       // small pinned host scratch for scalar read-back
+};
+
+int sphx_set_err(sphx_ctx* ctx, int code, const char* fmt, ...);
+int sphx_ensure(sphx_ctx* ctx, DevBuf& b, size_t bytes);
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return sphx_set_err(ctx, SPHX_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__,       \
+                                #expr, hipGetErrorString(e_));                               \
+    } while (0)
+#define SPHX_TRY(expr)                                                                       \
+    do {                                                                                     \
+        int r_ = (expr);                                                                     \
+        if (r_ != SPHX_OK) return r_;                                                        \
+    } while (0)
+
+static inline int64_t sphx_pad64(int64_t n) { return (n + 63) & ~int64_t(63); }
+
+// scalar slots in ctx->scal (8-byte units)
+enum {
+    SC_CT_BITS = 0,   // u64: min crossing time (bits of a positive double)
+    SC_DT = 1,        // f64: time step
+    SC_CAND = 2,      // u64: candidate evaluations
+    SC_RETRY = 3,     // u64: retried searches
+    SC_HSUM = 4,      // f64: sum of h (for the next grid's cell size)
+    SC_NSLOTS = 16
+};
+
+// ---- kernel launch wrappers (defined in the .hip files) ---------------------------------
+// grid
+int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
+              double out_minmax[6]);
+int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
+                    const double* z, double cell_hint);   // fills grid, cell_start, perm
+// knn
+struct KnnOut {
+    int32_t* nbr;       // [k][npad] sorted indices (nullable)
+    double* h_sorted;   // [n] in sorted order (nullable)
+    int64_t* idx64;     // (n,k) by id (nullable)
+    double* dist;       // (n,k) by id (nullable)
+    int64_t* nontriv;   // (n,) by id (nullable)
+    double* h_by_id;    // (n,) by id (nullable)
+};
+int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys,
+             const double* zs, const int32_t* id, const int32_t* inv, const double* rsearch,
+             double rscale, double rbound, const KnnOut& out);
+// sums
+int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
+              const double* pos_aos, const double* vx, const double* vy, const double* vz,
+              const double* vel_aos, const double* m, const double* h, const double* T,
+              const double* mu, const double* gam, const double* ptype);
+int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k);
+int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double* ptype);
+int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
+int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F);
+int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmajor);
+
+// integrate / layout helpers (sphx_integrate.hip)
+int sphx_clamp(sphx_ctx* ctx, int64_t n, StateArrays& s);
+int sphx_permute_state(sphx_ctx* ctx, int64_t n);
+int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h);
+int sphx_compute_dt(sphx_ctx* ctx, int first, double fixed_dt);
+int sphx_integrate(sphx_ctx* ctx, int64_t n);
+int sphx_aos_to_soa3(sphx_ctx* ctx, int64_t n, const double* aos, double* x, double* y, double* z);
+int sphx_soa3_to_aos_by_id(sphx_ctx* ctx, int64_t n, const int* id, const double* x, const double* y,
+                           const double* z, double* aos);
+int sphx_scatter_rows_by_id(sphx_ctx* ctx, int64_t n, int w, const int* id, const double* in, double* out);
+int sphx_gather3(sphx_ctx* ctx, int64_t n, const int* perm, const double* x, const double* y,
+                 const double* z, double* xs, double* ys, double* zs);
+int sphx_iota(sphx_ctx* ctx, int64_t n, int* out);

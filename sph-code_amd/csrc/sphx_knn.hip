@@ -1,0 +1,315 @@
+// sphx_knn.hip - exact k-nearest-neighbour search on a cell list (replaces nsc:541-552).
+//
+// One 64-wide wavefront per query particle; K <= 64 so the running top-64 candidate set lives
+// in registers, ONE ENTRY PER LANE, kept sorted by a bitonic network on (d^2 bits, id).
+//   * particles are cell-sorted (sphx_grid.hip); a row of cells cx0..cx1 at fixed (cy,cz) is
+//     one contiguous range of the sorted arrays, so candidate loads are coalesced SoA reads;
+//   * the rows of the search cube are flattened with a wave prefix sum so every batch of 64
+//     candidates uses all 64 lanes;
+//   * candidates below the current threshold (search radius, then the running K-th best) are
+//     ballot-compacted into a per-wave LDS staging ring; only when 64 survivors have
+//     accumulated does the wave pay for a 64-key bitonic sort + merge;
+//   * the search radius is per particle (previous h, or a cell-count density estimate); if
+//     fewer than K candidates lie inside it the same wave enlarges the radius and repeats, so
+//     the result is always the exact kNN (ties broken by particle id).
+// Distances are accumulated as ((dx*dx + dy*dy) + dz*dz) without FMA contraction, the same
+// arithmetic SciPy's cKDTree uses, so orderings agree with the oracle bit for bit.
+#include "sphx_internal.h"
+
+#define KNN_BLOCK 256
+#define KNN_PPB 64          // particles per workgroup (16 per wave)
+#define KNN_INF 0x7FF0000000000000ull
+#define KNN_MAX_TRIES 48
+
+struct KnnArgs {
+    int n, k, npad;
+    const double *x, *y, *z;
+    const int* id;
+    const int* inv;
+    const int* cell_start;
+    GridParams g;
+    const double* rsearch;
+    double rscale;
+    double rbound;
+    int* nbr;
+    double* h_sorted;
+    long long* idx64;
+    double* dist;
+    long long* nontriv;
+    double* h_by_id;
+    u64* counters;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ bool kv_less(u64 ka, u32 va, u64 kb, u32 vb) {
+    return ka < kb || (ka == kb && va < vb);
+}
+
+// compare-exchange with lane ^ j; keep_min: this lane keeps the smaller of the pair
+__device__ __forceinline__ void cmpx(u64& k, u32& v, int j, bool keep_min) {
+    u64 pk = __shfl_xor(k, j, 64);
+    u32 pv = __shfl_xor(v, j, 64);
+    bool p_lt = kv_less(pk, pv, k, v);
+    bool p_gt = kv_less(k, v, pk, pv);
+    bool take = keep_min ? p_lt : p_gt;
+    k = take ? pk : k;
+    v = take ? pv : v;
+}
+
+// full bitonic sort of 64 (key,id) pairs across the wave; descending if desc
+__device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            bool up = (((lane & size) == 0) != desc);
+            bool lower = (lane & j) == 0;
+            cmpx(k, v, j, lower == up);
+        }
+    }
+}
+
+// merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
+__device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
+    sort64(ck, cv, lane, true);
+    if (kv_less(ck, cv, bk, bv)) { bk = ck; bv = cv; }   // bitonic: min of asc and desc
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) cmpx(bk, bv, j, (lane & j) == 0);
+}
+
+__device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell, int nmax1) {
+    double t = (v - vmin) * inv_cell;
+    t = fmin(fmax(t, 0.0), (double)nmax1);
+    return (int)t;
+}
+
+__device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    double s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+__global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
+    __shared__ int tile[SPHX_MAX_K][KNN_PPB + 1];
+    __shared__ u64 stg_key[KNN_BLOCK / 64][128];
+    __shared__ u32 stg_id[KNN_BLOCK / 64][128];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int base = blockIdx.x * KNN_PPB;
+    const GridParams g = a.g;
+    const int K = a.k;
+    u64* skey = stg_key[wave];
+    u32* sid = stg_id[wave];
+    u64 ncand = 0, nretry = 0;
+
+    for (int t16 = 0; t16 < KNN_PPB / 4; ++t16) {
+        const int li = wave * (KNN_PPB / 4) + t16;
+        const int i = base + li;
+        if (i >= a.n) {                       // wave-uniform
+            if (lane < K) tile[lane][li] = -1;
+            continue;
+        }
+        const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
+        const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
+        const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
+        const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
+
+        double R = a.rsearch ? a.rsearch[i] * a.rscale : 0.0;
+        if (!(R > 0.0)) {
+            // density estimate from the 3x3x3 block of cells around the particle
+            int cnt = 0, nc = 0;
+            if (lane < 9) {
+                int cy = cyi - 1 + lane % 3, cz = czi - 1 + lane / 3;
+                if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+                    int xlo = max(cxi - 1, 0), xhi = min(cxi + 1, g.nx - 1);
+                    int row = (cz * g.ny + cy) * g.nx;
+                    cnt = a.cell_start[row + xhi + 1] - a.cell_start[row + xlo];
+                    nc = xhi - xlo + 1;
+                }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                cnt += __shfl_xor(cnt, o, 64);
+                nc += __shfl_xor(nc, o, 64);
+            }
+            cnt = __shfl(cnt, 0, 64);
+            nc = __shfl(nc, 0, 64);
+            double vol = (double)nc * g.cell * g.cell * g.cell;
+            double dens = (double)(cnt > 0 ? cnt : 1) / vol;
+            R = 1.3 * cbrt((double)K / (4.1887902047863905 * dens));
+        }
+        if (R > a.rbound) R = a.rbound;
+
+        u64 bk;
+        u32 bv;
+        int tries = 0;
+        bool done;
+        do {
+            bk = KNN_INF;
+            bv = 0xFFFFFFFFu;
+            // threshold: accept (key,id) < (tk,tv).  Inside the trial radius R the test is
+            // d2 <= R^2; at the caller's bound it is the strict d < dist of cKDTree.
+            const bool at_bound = (R >= a.rbound);
+            u64 tk = (u64)__double_as_longlong(R * R);
+            u32 tv = at_bound ? 0u : 0xFFFFFFFFu;
+            const int cx0 = cell_coord(xi - R, g.xmin, g.inv_cell, g.nx - 1);
+            const int cx1 = cell_coord(xi + R, g.xmin, g.inv_cell, g.nx - 1);
+            const int cy0 = cell_coord(yi - R, g.ymin, g.inv_cell, g.ny - 1);
+            const int cy1 = cell_coord(yi + R, g.ymin, g.inv_cell, g.ny - 1);
+            const int cz0 = cell_coord(zi - R, g.zmin, g.inv_cell, g.nz - 1);
+            const int cz1 = cell_coord(zi + R, g.zmin, g.inv_cell, g.nz - 1);
+            const int ysp = cy1 - cy0 + 1;
+            const int nrows = ysp * (cz1 - cz0 + 1);
+            int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
+
+            for (int rb = 0; rb < nrows; rb += 64) {
+                const int r = rb + lane;
+                int s_row = 0, cnt = 0;
+                if (r < nrows) {
+                    int cy = cy0 + r % ysp, cz = cz0 + r / ysp;
+                    int row = (cz * g.ny + cy) * g.nx;
+                    s_row = a.cell_start[row + cx0];
+                    cnt = a.cell_start[row + cx1 + 1] - s_row;
+                }
+                int incl = cnt;               // inclusive wave scan
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                const int off = incl - cnt;
+                const int T = __shfl(incl, 63, 64);
+                ncand += (u64)T;
+
+                for (int t0 = 0; t0 < T; t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool valid = t < T;
+                    const int tt = valid ? t : 0;
+                    int rr = 0;               // largest row with off[row] <= tt
+#pragma unroll
+                    for (int st = 32; st >= 1; st >>= 1) {
+                        int pr = rr + st;
+                        int v = __shfl(off, pr, 64);
+                        if (v <= tt) rr = pr;
+                    }
+                    const int p = __shfl(s_row, rr, 64) + (tt - __shfl(off, rr, 64));
+                    const double d2 = dist2_nofma(a.x[p] - xi, a.y[p] - yi, a.z[p] - zi);
+                    const u32 pid = (u32)a.id[p];
+                    const u64 key = (u64)__double_as_longlong(d2);
+                    // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass
+                    const bool keep = valid && kv_less(key, pid, tk, tv);
+                    const u64 mask = __ballot(keep);
+                    const int c = __popcll(mask);
+                    if (c) {
+                        if (keep) {
+                            int pos = (head + nst + __popcll(mask & ((1ull << lane) - 1ull))) & 127;
+                            skey[pos] = key;
+                            sid[pos] = pid;
+                        }
+                        nst += c;
+                        if (nst >= 64) {
+                            wave_sync();
+                            u64 ck = skey[(head + lane) & 127];
+                            u32 cv = sid[(head + lane) & 127];
+                            wave_sync();
+                            head = (head + 64) & 127;
+                            nst -= 64;
+                            merge64(bk, bv, ck, cv, lane);
+                            u64 kth = __shfl(bk, K - 1, 64);
+                            u32 kthv = __shfl(bv, K - 1, 64);
+                            if (kth != KNN_INF) { tk = kth; tv = kthv; }
+                        }
+                    }
+                }
+            }
+            if (nst > 0) {
+                wave_sync();
+                u64 ck = KNN_INF;
+                u32 cv = 0xFFFFFFFFu;
+                if (lane < nst) {
+                    ck = skey[(head + lane) & 127];
+                    cv = sid[(head + lane) & 127];
+                }
+                wave_sync();
+                merge64(bk, bv, ck, cv, lane);
+            }
+            const u64 kth = __shfl(bk, K - 1, 64);
+            const bool full = (kth != KNN_INF);
+            const bool covers = (cx0 == 0 && cy0 == 0 && cz0 == 0 && cx1 == g.nx - 1 &&
+                                 cy1 == g.ny - 1 && cz1 == g.nz - 1);
+            done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
+            if (!done) {
+                R *= 1.6;
+                if (R > a.rbound) R = a.rbound;
+                ++nretry;
+            }
+        } while (!done);
+
+        // ---- outputs: lanes 0..K-1 hold the neighbours in ascending (d2, id) order ----
+        const bool valid = (lane < K) && (bk != KNN_INF);
+        const int found = __popcll(__ballot(valid));
+        const double d = valid ? sqrt(__longlong_as_double((long long)bk)) : 0.0;
+        const double dlast = __shfl(d, found > 0 ? found - 1 : 0, 64);
+        const double hval = found > 0 ? dlast : 0.0;
+        const int oid = a.id[i];
+        if (lane < K) {
+            if (a.nbr) tile[lane][li] = valid ? a.inv[bv] : -1;
+            if (a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)bv : (long long)a.n;
+            if (a.dist) a.dist[(long long)oid * K + lane] = d;
+        }
+        if (lane == 0) {
+            if (a.h_sorted) a.h_sorted[i] = hval;
+            if (a.h_by_id) a.h_by_id[oid] = hval;
+            if (a.nontriv) a.nontriv[oid] = found;
+        }
+    }
+    if (a.nbr) {
+        __syncthreads();
+        for (int kk = wave; kk < K; kk += KNN_BLOCK / 64) {
+            int i = base + lane;
+            if (i < a.npad) a.nbr[(long long)kk * a.npad + i] = tile[kk][lane];
+        }
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[SC_CAND], ncand);
+        if (nretry) atomicAdd(&a.counters[SC_RETRY], nretry);
+    }
+}
+
+int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys,
+             const double* zs, const int32_t* id, const int32_t* inv, const double* rsearch,
+             double rscale, double rbound, const KnnOut& out) {
+    if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d not in 1..%d", k, SPHX_MAX_K);
+    if (n < 1 || n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
+    KnnArgs a;
+    a.n = (int)n;
+    a.k = k;
+    a.npad = (int)sphx_pad64(n);
+    a.x = xs; a.y = ys; a.z = zs;
+    a.id = id; a.inv = inv;
+    a.cell_start = ctx->cell_start.as<int>();
+    a.g = ctx->grid;
+    a.rsearch = rsearch;
+    a.rscale = rscale;
+    a.rbound = (rbound > 0.0) ? rbound : INFINITY;
+    a.nbr = out.nbr;
+    a.h_sorted = out.h_sorted;
+    a.idx64 = (long long*)out.idx64;
+    a.dist = out.dist;
+    a.nontriv = (long long*)out.nontriv;
+    a.h_by_id = out.h_by_id;
+    a.counters = ctx->scal.as<u64>();
+    if (a.nbr && !a.inv) return sphx_set_err(ctx, SPHX_E_ARG, "internal list needs the inverse permutation");
+    int blocks = (int)(sphx_pad64(n) / KNN_PPB);
+    hipLaunchKernelGGL(knn_kernel, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

@@ -1,0 +1,107 @@
+"""Seeded initial conditions of the BASELINE configs (np.random.RandomState,
+seed = 12345 + config number).  Array conventions follow sph/code_running.py:114-177.
+
+The named ICs do not exist in the reference; they are synthesised here:
+  C1 uniform sphere        R = 0.625e6 AU, m = 0.4 Msun/715, gas, T ~ U[10,20) K, v ~ N(0, 1 km/s)
+  C2 polytrope-like sphere n(r) ~ 1/((r/2e7 AU)^4 + 1), r <= 5e7 AU: the initial radial profile of
+                           imf/lane_emden_modified.py:317-343 sampled by inverse CDF
+  C3 Sedov-Taylor blast    uniform cold sphere + 1e44 J at the centre, 73.6 % kinetic (radial kick,
+                           nsc:1193-1201) / 26.4 % thermal (nsc:909), dealt to the innermost particles
+"""
+import numpy as np
+
+AU = 149597870700.0
+SOLAR = 1.989e30
+K_B = 1.380649e-23
+AMU = 1.66053906892e-27
+M_H = 1.0008 * AMU
+MU_SPECIE = np.array([2.0158, 4.0026, 1.0079, 1.0074, 4.0021, 4.0016, 0.0005, 140.69, 60.08, 12.0107,
+                      28.0855, 55.834, 100.39, 131.93, 40.096])
+GAMMA_SPECIE = np.array([7. / 5, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 15.6354113, 4.913,
+                         1.0125, 2.364, 3.02, 10., 10., 10.])
+F_GAS = np.array([.86, .14] + [0.] * 13)
+
+
+def _finish(pts, vel, mass, T, ptype=None, f_un=None):
+    n = len(pts)
+    ptype = np.zeros(n) if ptype is None else ptype
+    if f_un is None:
+        f_un = np.tile(F_GAS, (n, 1))
+    mu = np.sum(f_un * MU_SPECIE, axis=1) / np.sum(f_un, axis=1)        # drv:162
+    gam = np.sum(f_un * GAMMA_SPECIE, axis=1) / np.sum(f_un, axis=1)    # drv:163
+    E = gam * mass * K_B * T / (mu * M_H)                               # drv:166
+    return dict(points=np.ascontiguousarray(pts), velocities=np.ascontiguousarray(vel), mass=mass,
+                particle_type=ptype, f_un=f_un, T=T, mu_array=mu, gamma_array=gam, E_internal=E,
+                total_accel=np.zeros((n, 3)))
+
+
+def _unit_vectors(rs, n):
+    u = rs.normal(size=(n, 3))
+    return u / np.linalg.norm(u, axis=1)[:, None]
+
+
+def uniform_sphere(n, seed=12346, radius=0.625e6 * AU, sigma_v=1000.):
+    """C1."""
+    rs = np.random.RandomState(seed)
+    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * radius
+    mass = np.full(n, 0.4 * SOLAR / 715.)
+    T = 10. * (1. + rs.rand(n))
+    vel = rs.normal(size=(n, 3)) * sigma_v
+    return _finish(pts, vel, mass, T)
+
+
+def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000.):
+    """C2: radii by inverse CDF of M(<r) ~ int r^2/((r/a)^4+1) dr on the reference's radial grid
+    r = sqrt(linspace(0, 25e14, 2001)) AU (imf/lane_emden_modified.py:317-343)."""
+    rs = np.random.RandomState(seed)
+    r_grid = np.sqrt(np.linspace(0., (rmax / AU) ** 2, 2001)) * AU
+    dens = 1. / ((r_grid / a) ** 4 + 1.)
+    shell = 0.5 * (dens[1:] * r_grid[1:] ** 2 + dens[:-1] * r_grid[:-1] ** 2) * np.diff(r_grid)
+    cdf = np.concatenate([[0.], np.cumsum(shell)])
+    cdf /= cdf[-1]
+    r = np.interp(rs.rand(n), cdf, r_grid)
+    pts = _unit_vectors(rs, n) * r[:, None]
+    # equal-mass particles; total mass = mean density 1e-18 kg/m^3-scale cloud of the 1-D model
+    mass = np.full(n, 0.4 * SOLAR / 715.)
+    T = 10. * (1. + rs.rand(n))
+    vel = rs.normal(size=(n, 3)) * sigma_v
+    return _finish(pts, vel, mass, T)
+
+
+def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.28 * SOLAR):
+    """C3: cold uniform gas; the innermost `kick_mass` of gas receives 73.6 % of `energy` as a
+    radial kick and 26.4 % as heat."""
+    rs = np.random.RandomState(seed)
+    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * radius
+    mass = np.full(n, 0.4 * SOLAR / 715.)
+    T = 10. * (1. + rs.rand(n))
+    vel = rs.normal(size=(n, 3)) * 100.
+    r = np.linalg.norm(pts, axis=1)
+    order = np.argsort(r)
+    nk = max(int(round(kick_mass / mass[0])), 32)
+    nk = min(nk, n // 8)
+    inner = order[:nk]
+    ek = 0.736 * energy
+    vk = np.sqrt(2. * ek / np.sum(mass[inner]))
+    rhat = pts[inner] / np.maximum(r[inner], 1e-300)[:, None]
+    vel[inner] += vk * rhat
+    st = _finish(pts, vel, mass, T)
+    eth = 0.264 * energy / nk
+    st["E_internal"][inner] += eth
+    st["T"][inner] = st["E_internal"][inner] * (st["mu_array"][inner] * M_H) / \
+        (st["gamma_array"][inner] * mass[inner] * K_B)                   # drv:491
+    return st
+
+
+def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000.):
+    """C4: the reference's own IC (sph/code_running.py:62,132)."""
+    rs = np.random.RandomState(seed)
+    pts = (rs.rand(n, 3) - 0.5) * side
+    mass = np.full(n, 0.4 * SOLAR / 715.)
+    T = 10. * (1. + rs.rand(n))
+    vel = rs.normal(size=(n, 3)) * sigma_v
+    return _finish(pts, vel, mass, T)
+
+
+WORKLOADS = {"uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
+             "uniform_cube": uniform_cube}

@@ -1,0 +1,59 @@
+"""Device-resident step loop: the fused hot path of sph/code_running.py:217-491
+(search -> dt -> density/pressure/viscosity sums -> leapfrog), nothing leaves HBM between steps.
+
+State in, state out keeps the reference's array conventions (sph/code_running.py:114-177):
+points/velocities (N,3), mass, particle_type (f64 0/1/2), f_un (N,S), T, mu_array,
+gamma_array, E_internal, total_accel.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import dp, f64
+
+
+class Simulation:
+    def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.Context(device)
+        self.k = int(n_neigh)
+        self.dist = 0.0 if dist is None or not np.isfinite(dist) else float(dist)
+        self.first = True
+        pts = f64(state["points"])
+        n = pts.shape[0]
+        self.n = n
+        vel = f64(state["velocities"], (n, 3))
+        fu = f64(state["f_un"]) if (with_species and state.get("f_un") is not None) else None
+        acc = state.get("total_accel")
+        acc = f64(acc, (n, 3)) if acc is not None else None
+        c = self.ctx
+        c.check(c.lib.sphx_state_upload(
+            c.h, n, 0 if fu is None else fu.shape[1], dp(pts), dp(vel), dp(f64(state["mass"], (n,))),
+            dp(f64(state["particle_type"], (n,))), dp(fu), dp(f64(state["T"], (n,))),
+            dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
+            dp(f64(state["E_internal"], (n,))), dp(acc)))
+
+    def step(self, nsteps=1, fixed_dt=0.0):
+        c = self.ctx
+        c.check(c.lib.sphx_step(c.h, int(nsteps), self.k, self.dist, 1 if self.first else 0, float(fixed_dt)))
+        self.first = False
+
+    def download(self):
+        n = self.n
+        out = dict(points=np.empty((n, 3)), velocities=np.empty((n, 3)), total_accel=np.empty((n, 3)),
+                   E_internal=np.empty(n), T=np.empty(n), sizes=np.empty(n), densities=np.empty(n),
+                   num_densities=np.empty(n), visc_heat=np.empty(n))
+        dt = C.c_double(0.0)
+        c = self.ctx
+        c.check(c.lib.sphx_state_download(
+            c.h, dp(out["points"]), dp(out["velocities"]), dp(out["total_accel"]), dp(out["E_internal"]),
+            dp(out["T"]), dp(out["sizes"]), dp(out["densities"]), dp(out["num_densities"]),
+            dp(out["visc_heat"]), C.cast(C.byref(dt), _lib.c_double_p)))
+        out["dt"] = dt.value
+        return out
+
+    def stats(self):
+        return self.ctx.stats()
+
+    def reset_stats(self):
+        self.ctx.reset_stats()
