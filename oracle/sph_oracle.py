@@ -360,7 +360,8 @@ def clamp_state(points, velocities):
     return p, np.nan_to_num(velocities)
 
 
-def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1):
+def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1,
+         fixed_dt=0.0):
     """One pass of the hot path: search -> dt -> sums -> leapfrog update.
 
     state: dict with points, velocities, mass, particle_type, f_un, T, mu_array, gamma_array,
@@ -371,7 +372,7 @@ def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, 
     p, v = clamp_state(s["points"], s["velocities"])
     nb, _, _, _, h = neighbors(p, dist, n_neigh, eps, workers=workers)
     ct = crossing_time(nb, v, h, s["particle_type"])
-    dt = timestep(ct, first)
+    dt = fixed_dt if fixed_dt > 0 else timestep(ct, first)
     ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, s["f_un"], s["particle_type"],
                                                    s["T"], s["mu_array"], s["gamma_array"], v)
     gas = (np.asarray(s["particle_type"]) == 0.)[:, None]

@@ -1,6 +1,9 @@
 // sphx_integrate.hip - state permutation, time-step control and the leapfrog update
 // (restated from the driver text: drv:222-238 dt + clamps, drv:460-491 integrator).
 #include "sphx_internal.h"
+// NumPy never fuses a multiply into an add: keep every operation separately rounded so that
+// cancellations such as h_j^2 - r^2 at the kernel edge reproduce the reference bit for bit.
+#pragma clang fp contract(off)
 #include <float.h>
 
 __device__ __forceinline__ double nan_to_num(double v) {

@@ -3,6 +3,9 @@
 // driver-injected global d, clipped gradients, physical sign.  One thread per particle over
 // the K-major neighbour list; deltas are relative to the particle itself.
 #include "sphx_internal.h"
+// NumPy never fuses a multiply into an add: keep every operation separately rounded so that
+// cancellations such as h_j^2 - r^2 at the kernel edge reproduce the reference bit for bit.
+#pragma clang fp contract(off)
 #include <float.h>
 
 #define PI64 201.06192982974676      /* 64 pi */

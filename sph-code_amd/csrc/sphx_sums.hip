@@ -9,6 +9,9 @@
 // distance), in registers, with no atomics: results are bitwise reproducible.
 // Deltas are taken relative to nbr[0][i] (the reference subtracts neighbour 0, nsc:580-581).
 #include "sphx_internal.h"
+// NumPy never fuses a multiply into an add: keep every operation separately rounded so that
+// cancellations such as h_j^2 - r^2 at the kernel edge reproduce the reference bit for bit.
+#pragma clang fp contract(off)
 #include <float.h>
 
 struct PrepArgs {
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         if (j < 0) continue;
         const Rec1 q = r1[j];
         const double dx = q.x - xr, dy = q.y - yr, dz = q.z - zr;
-        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
+        const double r2 = r * r;                              // nsc:588 squares the rounded distance
         const double qj = q.h2 - r2;
         double W = q.c1 * (qj * qj * qj);                     // nsc:588
         W = (W < 0.0) ? 0.0 : W;                              // nsc:589
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         const RecV v = rv[j];
         const double Bj = Bw[j];
         const double dx = q.x - ref.x, dy = q.y - ref.y, dz = q.z - ref.z;
-        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double r2 = r * r;
         const double qj = q.h2 - r2, qi = hi2 - r2;
         const double cb = -6.0 * q.c1 * (qj * qj);
         const double ca = ci * (qi * qi);
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
         if (j < 0) continue;
         const Rec1 q = r1[j];
         const double dx = q.x - xr, dy = q.y - yr, dz = q.z - zr;
-        const double qj = q.h2 - (dx * dx + dy * dy + dz * dz);
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double qj = q.h2 - r * r;
         double W = q.c1 * (qj * qj * qj);
         W = (W < 0.0) ? 0.0 : W;
         const double wN = q.Nw * W;

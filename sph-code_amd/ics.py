@@ -103,5 +103,18 @@ def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000.):
     return _finish(pts, vel, mass, T)
 
 
+def cfl_dt(state, k=40, courant=0.25):
+    """A Courant-limited fixed step for violent ICs (the reference's dt >= dt_0/5 floor of
+    sph/code_running.py:226 is far above the crossing time of a 1e44 J blast at this scale):
+    courant * (mean kNN radius of a uniform fill) / (max speed + max sound speed)."""
+    pts = state["points"]
+    n = len(pts)
+    r = np.linalg.norm(pts - pts.mean(axis=0), axis=1).max()
+    hbar = (k / n) ** (1. / 3.) * r
+    cs = np.sqrt(state["gamma_array"] * K_B * state["T"] / (state["mu_array"] * AMU)).max()
+    vmax = np.linalg.norm(state["velocities"], axis=1).max()
+    return float(courant * hbar / (vmax + cs))
+
+
 WORKLOADS = {"uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
              "uniform_cube": uniform_cube}
