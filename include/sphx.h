@@ -77,6 +77,10 @@ const char* sphx_last_error(const sphx_ctx* ctx);
 int         sphx_version(void);
 int         sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c);
 int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
+/* Search tuning (performance only, never results): the step loop searches inside
+ * rscale * h_previous (default 1.2) and bins particles into cells of edge
+ * cell_factor * mean(h) (default 0.6).  Values <= 0 keep the current setting. */
+int         sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor);
 
 /* ---- nsc.neighbors(points, dist, N_NEIGH)                          nsc:541-552 ----- *
  * Exact k nearest neighbours (Euclidean) within `dist`; `eps` is accepted for API

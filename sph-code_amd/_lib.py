@@ -37,6 +37,7 @@ SIGNATURES = {
     "sphx_version": (C.c_int, []),
     "sphx_set_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
     "sphx_get_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
+    "sphx_set_tuning": (C.c_int, [_P, C.c_double, C.c_double]),
     "sphx_neighbors": (C.c_int, [_P, C.c_int64, C.c_int, _D, C.c_double, C.c_double, _I, _D, _I, _D]),
     "sphx_hydro_update": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _I] + [_D] * 9 + [C.c_int] + [_D] * 7),
     "sphx_density": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _I, C.c_double, _D]),
@@ -145,6 +146,9 @@ class Context:
         for k_, v in kw.items():
             setattr(c, k_, v)
         self.check(self.lib.sphx_set_constants(self.h, C.byref(c)))
+
+    def set_tuning(self, rscale=0.0, cell_factor=0.0):
+        self.check(self.lib.sphx_set_tuning(self.h, float(rscale), float(cell_factor)))
 
     def stats(self):
         s = SphxStats()

@@ -2,6 +2,7 @@
 // the reference's Python callables, and the device-resident step loop.
 #include "sphx_internal.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <new>
 
 int sphx_set_err(sphx_ctx* ctx, int code, const char* fmt, ...) {
@@ -61,6 +62,8 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     memset(&ctx->grid, 0, sizeof(ctx->grid));
     default_constants(&ctx->cst);
+    if (const char* e = getenv("SPHX_RSCALE")) { double v = atof(e); if (v >= 1.0) ctx->rscale = v; }
+    if (const char* e = getenv("SPHX_CELL")) { double v = atof(e); if (v > 0.0) ctx->cell_factor = v; }
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
@@ -113,6 +116,15 @@ extern "C" const char* sphx_last_error(const sphx_ctx* ctx) { return ctx ? ctx->
 extern "C" int sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c) {
     if (!ctx || !c) return SPHX_E_ARG;
     ctx->cst = *c;
+    return SPHX_OK;
+}
+extern "C" int sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor) {
+    if (!ctx) return SPHX_E_ARG;
+    if (rscale > 0.0) {
+        if (rscale < 1.0) return sphx_set_err(ctx, SPHX_E_ARG, "rscale %g < 1", rscale);
+        ctx->rscale = rscale;
+    }
+    if (cell_factor > 0.0) ctx->cell_factor = cell_factor;
     return SPHX_OK;
 }
 extern "C" int sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c) {
@@ -304,7 +316,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         if (ctx->step_count > 0) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             double hmean = *(double*)((char*)ctx->pinned + 256) / (double)n;
-            if (hmean > 0.0 && isfinite(hmean)) cell_hint = 0.6 * hmean;
+            if (hmean > 0.0 && isfinite(hmean)) cell_hint = ctx->cell_factor * hmean;
         }
         SPHX_TRY(sphx_build_grid(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), cell_hint));
     }
@@ -317,7 +329,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     o.h_sorted = s.hprev.as<double>();       // read as the search-radius hint, then overwritten
     o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr; o.h_by_id = nullptr;
     SPHX_TRY(sphx_knn(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), s.id.as<int>(),
-                      ctx->inv.as<int>(), s.hprev.as<double>(), 1.2, dist, o));
+                      ctx->inv.as<int>(), s.hprev.as<double>(), ctx->rscale, dist, o));
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
     SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,

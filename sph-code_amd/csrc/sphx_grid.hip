@@ -46,13 +46,14 @@ __global__ __launch_bounds__(RED_BLOCK) void bbox_partial(int n, const double* x
         partial[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void bbox_final(int nblocks, const double* partial, double* out) {
-    int c = threadIdx.x;
-    if (c < 6) {
-        double v = partial[c];
-        for (int b = 1; b < nblocks; ++b) v = c < 3 ? fmin(v, partial[b * 6 + c]) : fmax(v, partial[b * 6 + c]);
-        out[c] = v;
-    }
+// one wave per component: block c reduces partial[:, c]
+__global__ __launch_bounds__(64) void bbox_final(int nblocks, const double* partial, double* out) {
+    const int c = blockIdx.x;
+    double v = c < 3 ? INFINITY : -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+        v = c < 3 ? fmin(v, partial[b * 6 + c]) : fmax(v, partial[b * 6 + c]);
+    v = c < 3 ? wave_min(v) : wave_max(v);
+    if (threadIdx.x == 0) out[c] = v;
 }
 
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
@@ -63,7 +64,7 @@ int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     double* part = ctx->bbox_tmp.as<double>();
     double* fin = part + (size_t)RED_MAXBLOCKS * 6;
     hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, part);
-    hipLaunchKernelGGL(bbox_final, dim3(1), dim3(64), 0, ctx->stream, blocks, part, fin);
+    hipLaunchKernelGGL(bbox_final, dim3(6), dim3(64), 0, ctx->stream, blocks, part, fin);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->pinned, fin, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -184,10 +185,10 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     if (!(Lmax > 0.0)) Lmax = 1.0;
     double cell = cell_hint;
     if (!(cell > 0.0) || !isfinite(cell)) {
-        // mean kNN radius of a uniform fill of the box, times 0.6
+        // mean kNN radius of a uniform fill of the box, times cell_factor
         double V = 1.0;
         for (int c = 0; c < 3; ++c) V *= (L[c] > 1e-6 * Lmax ? L[c] : 1e-6 * Lmax);
-        cell = 0.6 * cbrt(V * (double)k / ((double)n * 4.1887902047863905));
+        cell = ctx->cell_factor * cbrt(V * (double)k / ((double)n * 4.1887902047863905));
     }
     if (cell < Lmax * 1e-4) cell = Lmax * 1e-4;
     int64_t cap = 8 * n + 1024;

@@ -22,20 +22,24 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-// Gather record of one particle (64 B, one half cache line): everything a neighbour
-// contributes to pass 1, so a neighbour costs one contiguous 64-B read.
-struct __attribute__((aligned(64))) Rec1 {
+// Gather record of one particle: ONE 128-B cache line holds everything any pass reads of a
+// neighbour, so each (particle, neighbour) pair touches exactly one line per pass.
+//   pass 1 reads [0..7]; pass 2 reads [0..3] + [8..12]; pass 3 reads [0..4] + [8..10] + [13].
+// rho / Bw are written by the owner's thread in pass 1 / pass 2 and read by others only in
+// the following kernel.
+struct __attribute__((aligned(128))) Rec {
     double x, y, z;   // position
     double h2;        // h_j^2
-    double c1;        // 315 / (64 pi h_j^9)                             nsc:588
-    double ms;        // +m (gas), -m (dust), 0 (star): m*[t==0], m*[t==2] nsc:605-606
-    double A;         // m/mu/amu*k*T*[t==0]   pressure weight            nsc:615
-    double Nw;        // m/mu/amu*[t==0]       number weight              nsc:607,626
-};
-// velocity record for the viscosity passes
-struct __attribute__((aligned(32))) RecV {
+    double c1;        // 315 / (64 pi h_j^9)                               nsc:588
+    double ms;        // +m (gas), -m (dust), 0 (star): m*[t==0], m*[t==2]  nsc:605-606
+    double A;         // m/mu/amu*k*T*[t==0]   pressure weight             nsc:615
+    double Nw;        // m/mu/amu*[t==0]       number weight               nsc:607,626
     double vx, vy, vz;
-    double cs;        // sqrt(gamma k T/mu/amu [t==0])                    nsc:647
+    double cs;        // sqrt(gamma k T/mu/amu [t==0])   neighbour form    nsc:647
+    double rho;       // written by pass 1                                  nsc:605
+    double Bw;        // m Pi [t==0], written by pass 2                     nsc:651
+    double csi;       // sqrt(gamma k T/(mu amu) [t==0]) own form           nsc:647
+    double h;         // smoothing length (crossing time)                   nsc:782
 };
 
 struct GridParams {
@@ -59,12 +63,13 @@ struct sphx_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     sphx_constants cst;
+    double rscale = 1.12, cell_factor = 0.6;    // search tuning (sphx_set_tuning)
     sphx_stats stats;
 
     // ---- working set (any particle order) ----
     int64_t n = 0, npad = 0;
     int k = 0, s = 0;
-    DevBuf rec1, recv;            // Rec1[n], RecV[n]
+    DevBuf rec1, recv;            // Rec[n] (recv unused)
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
     DevBuf rho, rhod, nden, G, Pi, Bw, csi, va, vh, ha, F;
     DevBuf relv;                  // per-particle max relative speed^2 (crossing time)

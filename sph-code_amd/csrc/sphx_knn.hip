@@ -50,36 +50,62 @@ __device__ __forceinline__ bool kv_less(u64 ka, u32 va, u64 kb, u32 vb) {
     return ka < kb || (ka == kb && va < vb);
 }
 
-// compare-exchange with lane ^ j; keep_min: this lane keeps the smaller of the pair
-__device__ __forceinline__ void cmpx(u64& k, u32& v, int j, bool keep_min) {
-    u64 pk = __shfl_xor(k, j, 64);
-    u32 pv = __shfl_xor(v, j, 64);
-    bool p_lt = kv_less(pk, pv, k, v);
-    bool p_gt = kv_less(k, v, pk, pv);
-    bool take = keep_min ? p_lt : p_gt;
+// ---- lane exchange lane ^ J without the LDS crossbar where the ISA allows it -----------------
+// DPP quad_perm / row_ror / row_half_mirror move data inside a row of 16 lanes in the VALU;
+// xor 16 uses ds_swizzle (no address VGPR), xor 32 the gfx950 v_permlane32_swap.
+template <int J> __device__ __forceinline__ u32 xchg32(u32 v) {
+    if constexpr (J == 1) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);        // row_half_mirror: ^7
+        return (u32)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]: ^3
+    } else if constexpr (J == 8) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);    // row_ror:8
+    } else if constexpr (J == 16) {
+        return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                      // bitmode xor 0x10
+    } else {
+        return (u32)__shfl_xor((int)v, 32, 64);
+    }
+}
+
+// compare-exchange with lane ^ J; keep_min: this lane keeps the smaller of the pair.
+// All (key,id) pairs are distinct except the (INF, ~0) padding, for which either choice is
+// the same value, so one lexicographic compare decides both directions.
+template <int J> __device__ __forceinline__ void cmpx(u64& k, u32& v, bool keep_min) {
+    const u32 plo = xchg32<J>((u32)k), phi = xchg32<J>((u32)(k >> 32));
+    const u64 pk = ((u64)phi << 32) | plo;
+    const u32 pv = xchg32<J>(v);
+    const bool p_lt = kv_less(pk, pv, k, v);
+    const bool take = (p_lt == keep_min);
     k = take ? pk : k;
     v = take ? pv : v;
 }
 
+template <int SIZE, int J> __device__ __forceinline__ void sort_stage(u64& k, u32& v, int lane, bool desc) {
+    const bool up = (((lane & SIZE) == 0) != desc);
+    const bool lower = (lane & J) == 0;
+    cmpx<J>(k, v, lower == up);
+    if constexpr (J > 1) sort_stage<SIZE, J / 2>(k, v, lane, desc);
+}
+template <int SIZE> __device__ __forceinline__ void sort_sizes(u64& k, u32& v, int lane, bool desc) {
+    if constexpr (SIZE > 2) sort_sizes<SIZE / 2>(k, v, lane, desc);
+    sort_stage<SIZE, SIZE / 2>(k, v, lane, desc);
+}
 // full bitonic sort of 64 (key,id) pairs across the wave; descending if desc
 __device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            bool up = (((lane & size) == 0) != desc);
-            bool lower = (lane & j) == 0;
-            cmpx(k, v, j, lower == up);
-        }
-    }
+    sort_sizes<64>(k, v, lane, desc);
 }
-
+template <int J> __device__ __forceinline__ void merge_stage(u64& k, u32& v, int lane) {
+    cmpx<J>(k, v, (lane & J) == 0);
+    if constexpr (J > 1) merge_stage<J / 2>(k, v, lane);
+}
 // merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
 __device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
     sort64(ck, cv, lane, true);
     if (kv_less(ck, cv, bk, bv)) { bk = ck; bv = cv; }   // bitonic: min of asc and desc
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) cmpx(bk, bv, j, (lane & j) == 0);
+    merge_stage<32>(bk, bv, lane);
 }
 
 __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell, int nmax1) {
@@ -169,6 +195,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
             const int ysp = cy1 - cy0 + 1;
             const int nrows = ysp * (cz1 - cz0 + 1);
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
+            bool have_best = false;           // best[] still empty: first flush is a plain sort
 
             for (int rb = 0; rb < nrows; rb += 64) {
                 const int r = rb + lane;
@@ -202,9 +229,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
                     }
                     const int p = __shfl(s_row, rr, 64) + (tt - __shfl(off, rr, 64));
                     const double d2 = dist2_nofma(a.x[p] - xi, a.y[p] - yi, a.z[p] - zi);
-                    const u32 pid = (u32)a.id[p];
                     const u64 key = (u64)__double_as_longlong(d2);
-                    // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass
+                    // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass.
+                    // The id (tie-break) is only fetched for lanes that can still qualify.
+                    u32 pid = 0xFFFFFFFFu;
+                    if (valid && key <= tk) pid = (u32)a.id[p];
                     const bool keep = valid && kv_less(key, pid, tk, tv);
                     const u64 mask = __ballot(keep);
                     const int c = __popcll(mask);
@@ -222,7 +251,13 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
                             wave_sync();
                             head = (head + 64) & 127;
                             nst -= 64;
-                            merge64(bk, bv, ck, cv, lane);
+                            if (have_best) {
+                                merge64(bk, bv, ck, cv, lane);
+                            } else {
+                                sort64(ck, cv, lane, false);
+                                bk = ck; bv = cv;
+                                have_best = true;
+                            }
                             u64 kth = __shfl(bk, K - 1, 64);
                             u32 kthv = __shfl(bv, K - 1, 64);
                             if (kth != KNN_INF) { tk = kth; tv = kthv; }
@@ -239,7 +274,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
                     cv = sid[(head + lane) & 127];
                 }
                 wave_sync();
-                merge64(bk, bv, ck, cv, lane);
+                if (have_best) {
+                    merge64(bk, bv, ck, cv, lane);
+                } else {
+                    sort64(ck, cv, lane, false);
+                    bk = ck; bv = cv;
+                }
             }
             const u64 kth = __shfl(bk, K - 1, 64);
             const bool full = (kth != KNN_INF);

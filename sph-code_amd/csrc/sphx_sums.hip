@@ -1,7 +1,7 @@
 // sphx_sums.hip - kernel-weighted SPH summations of nsc.hydro_update (nsc:556-671).
 //
 // Three dependent passes over a K-major int32 neighbour list nbr[k][npad] (coalesced for one
-// thread per particle), gathering 64-B / 32-B packed neighbour records (Rec1 / RecV):
+// thread per particle), gathering one 128-B record per neighbour (struct Rec):
 //   pass 1  rho, rho_dust, n, grad P            needs h_j        nsc:588-619
 //   pass 2  Pi_i = sum_k pi_ik, crossing time   needs rho_j      nsc:639-649, nsc:776-786
 //   pass 3  viscous accel + heat                needs Pi_j       nsc:651-654
@@ -20,7 +20,7 @@ struct PrepArgs {
     const double *vx, *vy, *vz; int vs;
     const double *m, *h, *T, *mu, *gam, *ptype;
     double kB, amu;
-    Rec1* r1; RecV* rv; double* csi;
+    Rec* rec;
 };
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     if (i >= a.n) return;
     const double m = a.m[i], h = a.h[i], T = a.T[i], mu = a.mu[i], gam = a.gam[i], pt = a.ptype[i];
     const double g = (pt == 0.0) ? 1.0 : 0.0;
-    Rec1 r;
+    Rec r;
     r.x = a.x[(size_t)i * a.ps]; r.y = a.y[(size_t)i * a.ps]; r.z = a.z[(size_t)i * a.ps];
     const double h2 = h * h, h4 = h2 * h2, h8 = h4 * h4;
     r.h2 = h2;
@@ -37,23 +37,20 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     const double nw = m / mu / a.amu;
     r.A = nw * a.kB * T * g;                                  // nsc:615
     r.Nw = nw * g;                                            // nsc:607, nsc:626
-    a.r1[i] = r;
-    if (a.rv) {
-        RecV v;
-        v.vx = a.vx[(size_t)i * a.vs]; v.vy = a.vy[(size_t)i * a.vs]; v.vz = a.vz[(size_t)i * a.vs];
-        v.cs = sqrt(gam * a.kB * T / mu / a.amu * g);         // nsc:647 neighbour form
-        a.rv[i] = v;
-        a.csi[i] = sqrt(gam * a.kB * T / (mu * a.amu) * g);   // nsc:647 own form
-    }
+    r.vx = a.vx[(size_t)i * a.vs]; r.vy = a.vy[(size_t)i * a.vs]; r.vz = a.vz[(size_t)i * a.vs];
+    r.cs = sqrt(gam * a.kB * T / mu / a.amu * g);             // nsc:647 neighbour form
+    r.rho = 0.0;
+    r.Bw = 0.0;
+    r.csi = sqrt(gam * a.kB * T / (mu * a.amu) * g);          // nsc:647 own form
+    r.h = h;
+    a.rec[i] = r;
 }
 
 int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
               const double* pos_aos, const double* vx, const double* vy, const double* vz,
               const double* vel_aos, const double* m, const double* h, const double* T,
               const double* mu, const double* gam, const double* ptype) {
-    SPHX_TRY(sphx_ensure(ctx, ctx->rec1, (size_t)n * sizeof(Rec1)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->recv, (size_t)n * sizeof(RecV)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->csi, (size_t)n * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->rec1, (size_t)n * sizeof(Rec)));
     PrepArgs a;
     a.n = (int)n;
     if (pos_aos) { a.x = pos_aos; a.y = pos_aos + 1; a.z = pos_aos + 2; a.ps = 3; }
@@ -62,9 +59,7 @@ int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     else { a.vx = vx; a.vy = vy; a.vz = vz; a.vs = 1; }
     a.m = m; a.h = h; a.T = T; a.mu = mu; a.gam = gam; a.ptype = ptype;
     a.kB = ctx->cst.k_B; a.amu = ctx->cst.amu;
-    a.r1 = ctx->rec1.as<Rec1>();
-    a.rv = (a.vx != nullptr) ? ctx->recv.as<RecV>() : nullptr;
-    a.csi = ctx->csi.as<double>();
+    a.rec = ctx->rec1.as<Rec>();
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -93,40 +88,51 @@ int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_dev) {
     return SPHX_OK;
 }
 
+// 32-B pieces of a record, loaded as two 16-B vectors each
+struct Q4 { double a, b, c, d; };
+__device__ __forceinline__ Q4 load4(const double* p) {
+    const double2 lo = *reinterpret_cast<const double2*>(p);
+    const double2 hi = *reinterpret_cast<const double2*>(p + 2);
+    return Q4{lo.x, lo.y, hi.x, hi.y};
+}
+
 // ---- pass 1 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                           const Rec1* __restrict__ r1, double* rho,
-                                                           double* rhod, double* nden, double* G,
-                                                           double* ha) {
+                                                           Rec* rec, double* rho, double* rhod,
+                                                           double* nden, double* G, double* ha) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Rec1 self = r1[i];
+    const double* self = reinterpret_cast<const double*>(&rec[i]);
+    const Q4 s0 = load4(self), s1 = load4(self + 4);          // x y z h2 | c1 ms A Nw
     int j0 = nbr[i];
-    double xr = self.x, yr = self.y, zr = self.z;
-    if (j0 >= 0 && j0 != i) { xr = r1[j0].x; yr = r1[j0].y; zr = r1[j0].z; }
-    const double hi2 = self.h2, ci = -6.0 * self.c1, Ai = self.A;
+    double xr = s0.a, yr = s0.b, zr = s0.c;
+    if (j0 >= 0 && j0 != i) { xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
+    const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
     double s_rho = 0.0, s_rd = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
     for (int kk = 0; kk < k; ++kk) {
         int j = nbr[(size_t)kk * npad + i];
         if (j < 0) continue;
-        const Rec1 q = r1[j];
-        const double dx = q.x - xr, dy = q.y - yr, dz = q.z - zr;
+        const double* q = reinterpret_cast<const double*>(&rec[j]);
+        const Q4 q0 = load4(q), q1 = load4(q + 4);
+        const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
         const double r2 = r * r;                              // nsc:588 squares the rounded distance
-        const double qj = q.h2 - r2;
-        double W = q.c1 * (qj * qj * qj);                     // nsc:588
+        const double qj = q0.d - r2;
+        const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
+        double W = c1 * (qj * qj * qj);                       // nsc:588
         W = (W < 0.0) ? 0.0 : W;                              // nsc:589
-        const double cb = -6.0 * q.c1 * (qj * qj);            // nsc:591 (not clipped)
+        const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
         const double qi = hi2 - r2;
         const double ca = ci * (qi * qi);                     // nsc:592
-        s_rho += fmax(q.ms, 0.0) * W;                         // nsc:605
-        s_rd += fmax(-q.ms, 0.0) * W;                         // nsc:606
-        s_n += q.Nw * W;                                      // nsc:607
-        gx += (q.A * (cb * dx) + Ai * (ca * dx)) * 0.5;       // nsc:615
-        gy += (q.A * (cb * dy) + Ai * (ca * dy)) * 0.5;
-        gz += (q.A * (cb * dz) + Ai * (ca * dz)) * 0.5;
+        s_rho += fmax(ms, 0.0) * W;                           // nsc:605
+        s_rd += fmax(-ms, 0.0) * W;                           // nsc:606
+        s_n += Nw * W;                                        // nsc:607
+        gx += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;        // nsc:615
+        gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
+        gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
     }
     rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+    rec[i].rho = s_rho;                                       // read by pass 2 (next kernel)
     G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
     ha[3 * (size_t)i + 0] = -gx / s_rho;                      // nsc:619
     ha[3 * (size_t)i + 1] = -gy / s_rho;
@@ -140,7 +146,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
     hipLaunchKernelGGL(pass_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec1>(),
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
                        ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
@@ -163,43 +169,38 @@ __device__ __forceinline__ u64 block_min_u64(u64 v) {
 }
 
 __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                      const Rec1* __restrict__ r1,
-                                                      const RecV* __restrict__ rv,
-                                                      const double* __restrict__ rho,
-                                                      const double* __restrict__ csi,
-                                                      const double* __restrict__ h,
-                                                      double* Pi, double* Bw, u64* ct_bits) {
+                                                      Rec* rec, double* Pi, u64* ct_bits) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
     if (i < n) {
-        const Rec1 self = r1[i];
+        const Rec* self = &rec[i];
         int j0 = nbr[i];
         if (j0 < 0) j0 = i;
-        const Rec1 ref = r1[j0];
-        const RecV vref = rv[j0];
-        const double rho_i = rho[i], cs_i = csi[i];
+        const double* rq = reinterpret_cast<const double*>(&rec[j0]);
+        const Q4 r0 = load4(rq), rv = load4(rq + 8);          // x y z h2 | vx vy vz cs
+        const double rho_i = self->rho, cs_i = self->csi, ms_i = self->ms, h_i = self->h;
         double s_pi = 0.0, maxrel = 0.0;
         for (int kk = 0; kk < k; ++kk) {
             int j = nbr[(size_t)kk * npad + i];
             if (j < 0) continue;
-            const double4 qa = *reinterpret_cast<const double4*>(&r1[j]);   // x,y,z,h2
-            const RecV v = rv[j];
-            const double dx = qa.x - ref.x, dy = qa.y - ref.y, dz = qa.z - ref.z;
-            const double dvx = v.vx - vref.vx, dvy = v.vy - vref.vy, dvz = v.vz - vref.vz;
+            const double* q = reinterpret_cast<const double*>(&rec[j]);
+            const Q4 q0 = load4(q), qv = load4(q + 8);
+            const double rho_j = q[12];
+            const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+            const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
             const double r2 = dx * dx + dy * dy + dz * dz;
             const double dot = dvx * dx + dvy * dy + dvz * dz;
-            double w = dot / sqrt(r2 + 0.01 * qa.w);                        // nsc:643
+            double w = dot / sqrt(r2 + 0.01 * q0.d);                        // nsc:643
             w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
-            const double rho_ab = (rho[j] + rho_i) / 2.0;                   // nsc:646
-            const double c_ab = 0.5 * (v.cs + cs_i);                        // nsc:647
+            const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
+            const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
             s_pi += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;             // nsc:649
             maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);       // nsc:780
         }
         Pi[i] = s_pi;
-        const double mg = fmax(self.ms, 0.0);
-        Bw[i] = mg * s_pi;                                                  // m Pi [t==0]  nsc:651
-        if (self.ms > 0.0) {                                                // gas only     nsc:782
-            double ct = h[i] / sqrt(maxrel);
+        rec[i].Bw = fmax(ms_i, 0.0) * s_pi;                                 // m Pi [t==0]  nsc:651
+        if (ms_i > 0.0) {                                                   // gas only     nsc:782
+            double ct = h_i / sqrt(maxrel);
             if (ct != ct) ct = 0.0;                                         // nan_to_num
             if (ct > DBL_MAX) ct = DBL_MAX;
             if (ct > 0.0) my_ct = (u64)__double_as_longlong(ct);
@@ -210,52 +211,48 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
 }
 
 int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double* ptype) {
-    (void)ptype;
+    (void)ptype; (void)h;
     SPHX_TRY(sphx_ensure(ctx, ctx->Pi, (size_t)n * sizeof(double)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec1>(),
-                       ctx->recv.as<RecV>(), ctx->rho.as<double>(), ctx->csi.as<double>(), h,
-                       ctx->Pi.as<double>(), ctx->Bw.as<double>(), ct);
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
+                       ctx->Pi.as<double>(), ct);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
 
 // ---- pass 3 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                        const Rec1* __restrict__ r1,
-                                                        const RecV* __restrict__ rv,
-                                                        const double* __restrict__ Bw,
+                                                        const Rec* __restrict__ rec,
                                                         const double* __restrict__ m, double* va,
                                                         double* vh) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Rec1 self = r1[i];
+    const Rec* self = &rec[i];
     int j0 = nbr[i];
     if (j0 < 0) j0 = i;
-    const Rec1 ref = r1[j0];
-    const RecV vref = rv[j0];
-    const double hi2 = self.h2, ci = -6.0 * self.c1, Bi = Bw[i];
+    const double* rq = reinterpret_cast<const double*>(&rec[j0]);
+    const Q4 r0 = load4(rq), rv = load4(rq + 8);
+    const double hi2 = self->h2, ci = -6.0 * self->c1, Bi = self->Bw;
     double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
     for (int kk = 0; kk < k; ++kk) {
         int j = nbr[(size_t)kk * npad + i];
         if (j < 0) continue;
-        const Rec1 q = r1[j];
-        const RecV v = rv[j];
-        const double Bj = Bw[j];
-        const double dx = q.x - ref.x, dy = q.y - ref.y, dz = q.z - ref.z;
+        const double* q = reinterpret_cast<const double*>(&rec[j]);
+        const Q4 q0 = load4(q), qv = load4(q + 8);
+        const double c1 = q[4], Bj = q[13];
+        const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const double r2 = r * r;
-        const double qj = q.h2 - r2, qi = hi2 - r2;
-        const double cb = -6.0 * q.c1 * (qj * qj);
+        const double qj = q0.d - r2, qi = hi2 - r2;
+        const double cb = -6.0 * c1 * (qj * qj);
         const double ca = ci * (qi * qi);
         const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
         const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
         const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
         ax += bx; ay += by; az += bz;
-        heat += bx * (v.vx - vref.vx) + by * (v.vy - vref.vy) + bz * (v.vz - vref.vz);   // nsc:653
+        heat += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
     }
     va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
     vh[i] = heat * m[i] / 2.0;                                              // nsc:654
@@ -265,9 +262,8 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->va, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec1>(),
-                       ctx->recv.as<RecV>(), ctx->Bw.as<double>(), m, ctx->va.as<double>(),
-                       ctx->vh.as<double>());
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(), m,
+                       ctx->va.as<double>(), ctx->vh.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -276,27 +272,29 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
 #define SPEC_CHUNK 8
 __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int k, int S,
                                                            const int* __restrict__ nbr,
-                                                           const Rec1* __restrict__ r1,
+                                                           const Rec* __restrict__ rec,
                                                            const double* __restrict__ fun, double* F) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s0 = blockIdx.y * SPEC_CHUNK;
     int j0 = nbr[i];
     if (j0 < 0) j0 = i;
-    const double xr = r1[j0].x, yr = r1[j0].y, zr = r1[j0].z;
+    const double xr = rec[j0].x, yr = rec[j0].y, zr = rec[j0].z;
     double acc[SPEC_CHUNK];
 #pragma unroll
     for (int q = 0; q < SPEC_CHUNK; ++q) acc[q] = 0.0;
     for (int kk = 0; kk < k; ++kk) {
         int j = nbr[(size_t)kk * npad + i];
         if (j < 0) continue;
-        const Rec1 q = r1[j];
-        const double dx = q.x - xr, dy = q.y - yr, dz = q.z - zr;
+        const double* q = reinterpret_cast<const double*>(&rec[j]);
+        const Q4 q0 = load4(q);
+        const double c1 = q[4], Nw = q[7];
+        const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        const double qj = q.h2 - r * r;
-        double W = q.c1 * (qj * qj * qj);
+        const double qj = q0.d - r * r;
+        double W = c1 * (qj * qj * qj);
         W = (W < 0.0) ? 0.0 : W;
-        const double wN = q.Nw * W;
+        const double wN = Nw * W;
         const double* f = fun + (size_t)j * S + s0;
 #pragma unroll
         for (int t = 0; t < SPEC_CHUNK; ++t)
@@ -310,7 +308,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F) {
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)((s + SPEC_CHUNK - 1) / SPEC_CHUNK));
     hipLaunchKernelGGL(pass_species_kernel, grid, dim3(256), 0, ctx->stream, (int)n,
-                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<Rec1>(), fun, F);
+                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(), fun, F);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
