@@ -107,6 +107,15 @@ int sphx_ensure(sphx_ctx* ctx, DevBuf& b, size_t bytes);
 
 static inline int64_t sphx_pad64(int64_t n) { return (n + 63) & ~int64_t(63); }
 
+// XCD-aware block remap: workgroups are dealt round-robin over the 8 XCDs (block b runs on
+// XCD b % 8, each with its own 4 MiB L2).  Map the blocks of one XCD onto one CONTIGUOUS
+// chunk of the (cell-sorted) particle range so an XCD's L2 only ever sees its own spatial
+// slab plus a halo.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, s = b >> 3;
+    return x * q + (x < r ? x : r) + s;
+}
+
 // scalar slots in ctx->scal (8-byte units)
 enum {
     SC_CT_BITS = 0,   // u64: min crossing time (bits of a positive double)

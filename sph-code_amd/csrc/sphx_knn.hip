@@ -129,7 +129,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int base = blockIdx.x * KNN_PPB;
+    const int base = xcd_block(blockIdx.x, gridDim.x) * KNN_PPB;
     const GridParams g = a.g;
     const int K = a.k;
     u64* skey = stg_key[wave];

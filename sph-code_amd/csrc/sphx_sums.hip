@@ -100,7 +100,7 @@ __device__ __forceinline__ Q4 load4(const double* p) {
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                            Rec* rec, double* rho, double* rhod,
                                                            double* nden, double* G, double* ha) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* self = reinterpret_cast<const double*>(&rec[i]);
     const Q4 s0 = load4(self), s1 = load4(self + 4);          // x y z h2 | c1 ms A Nw
@@ -170,7 +170,7 @@ __device__ __forceinline__ u64 block_min_u64(u64 v) {
 
 __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                       Rec* rec, double* Pi, u64* ct_bits) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
     if (i < n) {
         const Rec* self = &rec[i];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
                                                         const Rec* __restrict__ rec,
                                                         const double* __restrict__ m, double* va,
                                                         double* vh) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Rec* self = &rec[i];
     int j0 = nbr[i];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
                                                            const int* __restrict__ nbr,
                                                            const Rec* __restrict__ rec,
                                                            const double* __restrict__ fun, double* F) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s0 = blockIdx.y * SPEC_CHUNK;
     int j0 = nbr[i];
