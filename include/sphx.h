@@ -162,6 +162,43 @@ int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, double* accel,
 int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out);
 int sphx_reset_stats(sphx_ctx* ctx);
 
+/* ---- device-pointer building blocks for spatially decomposed (multi-GPU) runs ---------- *
+ * A rank holds n_total = n_owned + n_ghost particles in the caller's order, owned first
+ * (ghost = copy of a particle owned by another rank, sph_code_amd/multigpu.py).  Searches
+ * and sums are computed for the owned particles only; every output array has n_total rows in
+ * the caller's order with the owned rows written.  Between the calls the caller fills the
+ * ghost rows of h, rho and m*Pi from their owners (RCCL halo exchange), because the kernel
+ * uses the NEIGHBOUR's h (nsc:587-588), rho (nsc:646) and Pi (nsc:651).  All pointers are
+ * DEVICE pointers; work is queued on the context's stream (sphx_set_stream: e.g. torch's
+ * current stream, so no extra synchronisation is needed).                                  */
+int sphx_set_stream(sphx_ctx* ctx, void* hip_stream /* a hipStream_t; NULL = HIP's default stream */);
+int sphx_reset_stream(sphx_ctx* ctx);            /* back to the context's own stream */
+int sphx_sync(sphx_ctx* ctx);
+/* mean smoothing length of the previous search (sets the cell size of the next grid)     */
+int sphx_dev_set_mean_h(sphx_ctx* ctx, double mean_h);
+/* nsc.neighbors over owned+ghost candidates, owned queries.  pos (n_total,3); hint (n_total)
+ * previous h per particle or NULL; rscale <= 0: context default; h_out (n_total).          */
+int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, int k, const double* pos,
+                    const double* hint, double rscale, double dist, double* h_out);
+/* gather records; h must be complete (owned from sphx_dev_search, ghosts from their owners) */
+int sphx_dev_prep(sphx_ctx* ctx, const double* pos, const double* vel, const double* mass,
+                  const double* h, const double* T, const double* mu, const double* gamma,
+                  const double* ptype);
+/* nsc:588-619; outputs (n_total,) / (n_total,3), any may be NULL                            */
+int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, double* nden, double* hydro_accel);
+/* nsc:639-649 + nsc:776-786; rho_complete (n_total); ct_out: device double = min crossing
+ * time over the owned gas particles, or 0x7F7F7F7F7F7F7F7F (~1.4e306) when there is none     */
+int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi, double* Bw, double* ct_out);
+/* nsc:651-654; Bw_complete (n_total) = m Pi [t==0]; mass (n_total)                           */
+int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const double* mass, double* visc_accel,
+                  double* visc_heat);
+/* drv:233-238 and drv:460-491 on caller-order (n,3) arrays                                   */
+int sphx_dev_clamp(sphx_ctx* ctx, int64_t n, double* pos, double* vel);
+int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                       double* E_internal, double* T, const double* mass, const double* mu,
+                       const double* gamma, const double* ptype, const double* hydro_accel,
+                       const double* visc_accel, const double* visc_heat, double dt);
+
 #ifdef __cplusplus
 }
 #endif

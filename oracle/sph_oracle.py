@@ -110,12 +110,14 @@ def _pair_geometry(nb, pts, vel, h, lo, hi):
 
 
 def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array, gamma_array,
-                 velocities, chunk=32768, return_intermediates=False):
+                 velocities, chunk=32768, return_intermediates=False, rho_in=None, Bj_in=None):
     """Restatement of nsc:556-671 with the axis repair of SURVEY F5 (Pi_i = sum_k pi_ik).
 
     Returns (hydro_accel (N,3), visc_accel (N,3), visc_heat (N,), density (N,),
     num_density (N,), f_un_neighbor (S,N), dust_density (N,)) - nsc:671 - with the
     reference's sign convention (+grad P / rho).  Rows with idx == N contribute 0.
+    rho_in / Bj_in replace the neighbour-side rho_j (nsc:646) and m Pi_j [t==0] (nsc:651) - used
+    by the domain-decomposition tests, where ghost rows carry values computed by their owners.
     """
     nb = np.asarray(neighbor).astype(np.int64)
     pts = np.asarray(points, dtype=np.float64)
@@ -162,6 +164,9 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
         hydro_accel = G / rho[:, None]                                        # nsc:619
 
     # --- viscosity: Pi_i (axis-0 repair of nsc:649) ------------------------------------------
+    rho_out = rho
+    if rho_in is not None:
+        rho = np.asarray(rho_in, dtype=np.float64)
     Pi = np.zeros(n)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
@@ -181,17 +186,21 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
 
     visc_accel = np.zeros((n, 3)); visc_heat = np.zeros(n)
     Bj = m * Pi * gas                                                         # nsc:651
+    Bj_own = Bj
+    if Bj_in is not None:
+        Bj = np.asarray(Bj_in, dtype=np.float64)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
         j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi)
         B = ((np.where(valid, Bj[j], 0.) * cb)[..., None] * dx
-             + (Bj[lo:hi][:, None] * ca)[..., None] * dx) / 2.
+             + (Bj_own[lo:hi][:, None] * ca)[..., None] * dx) / 2.
         visc_accel[lo:hi] = -np.sum(B, axis=1)                                # nsc:651-652
         visc_heat[lo:hi] = np.sum(B * dv, axis=(1, 2)) * m[lo:hi] / 2.        # nsc:653-654
-    out = (hydro_accel, visc_accel, visc_heat, rho, nden, F, rho_d)
+    out = (hydro_accel, visc_accel, visc_heat, rho_out, nden, F, rho_d)
     if return_intermediates:
         inter = {k_: np.concatenate(v, axis=0) for k_, v in inter.items()}
         inter["Pi"] = Pi
+        inter["Bw"] = Bj_own
         inter["pressure_grad_symmetrized"] = G.T
         return out, inter
     return out
@@ -360,6 +369,27 @@ def clamp_state(points, velocities):
     return p, np.nan_to_num(velocities)
 
 
+def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type, ha, va, vh, dt,
+              grav_accel=None):
+    """drv:460-491: acceleration assembly (physical sign), viscous limiter, leapfrog,
+    energy.  Returns (points, velocities, total_accel, E_internal, T)."""
+    gas = (np.asarray(particle_type) == 0.)[:, None]
+    with np.errstate(all="ignore"):
+        pressure_accel = np.nan_to_num(-ha * gas)                              # drv:460
+        visc = np.nan_to_num(-va * gas)
+        vn = np.sqrt(np.sum(v ** 2, axis=1)); an = np.sqrt(np.sum(visc ** 2, axis=1))
+        lim = (vn - an * dt) < 0                                               # drv:475
+        visc = np.where(lim[:, None], -v / dt, visc)
+        total = pressure_accel + visc
+        if grav_accel is not None:
+            total = total + grav_accel                                         # drv:477
+        p = p + (total * dt ** 2) / 2. + v * dt                                # drv:481
+        v = v + (total + old) / 2. * dt                                        # drv:482-486
+        E = np.nan_to_num(E_internal) + np.nan_to_num(vh * dt)                 # drv:490
+        T = np.nan_to_num(E * (mu_array * M_H) / (gamma_array * mass * K_B))   # drv:491
+    return p, v, total, E, T
+
+
 def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1,
          fixed_dt=0.0):
     """One pass of the hot path: search -> dt -> sums -> leapfrog update.
@@ -373,22 +403,13 @@ def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, 
     nb, _, _, _, h = neighbors(p, dist, n_neigh, eps, workers=workers)
     ct = crossing_time(nb, v, h, s["particle_type"])
     dt = fixed_dt if fixed_dt > 0 else timestep(ct, first)
-    ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, s["f_un"], s["particle_type"],
+    fu = s.get("f_un")
+    if fu is None:                       # light ICs do not carry the (N,15) composition
+        fu = np.ones((len(p), 1))
+    ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, fu, s["particle_type"],
                                                    s["T"], s["mu_array"], s["gamma_array"], v)
-    gas = (np.asarray(s["particle_type"]) == 0.)[:, None]
-    pressure_accel = np.nan_to_num(-ha * gas)                                  # drv:460
-    visc = np.nan_to_num(-va * gas)
-    vn = np.sqrt(np.sum(v ** 2, axis=1)); an = np.sqrt(np.sum(visc ** 2, axis=1))
-    lim = (vn - an * dt) < 0                                                   # drv:475
-    visc = np.where(lim[:, None], -v / dt, visc)
-    total = pressure_accel + visc
-    if grav_accel is not None:
-        total = total + grav_accel                                             # drv:477
-    old = s["total_accel"]
-    p = p + (total * dt ** 2) / 2. + v * dt                                    # drv:481
-    v = v + (total + old) / 2. * dt                                            # drv:482-486
-    E = np.nan_to_num(s["E_internal"]) + np.nan_to_num(vh * dt)               # drv:490
-    T = np.nan_to_num(E * (s["mu_array"] * M_H) / (s["gamma_array"] * s["mass"] * K_B))  # drv:491
+    p, v, total, E, T = integrate(p, v, s["total_accel"], s["E_internal"], s["mass"], s["mu_array"],
+                                  s["gamma_array"], s["particle_type"], ha, va, vh, dt, grav_accel)
     s.update(points=p, velocities=v, total_accel=total, E_internal=E, T=T, dt=dt, sizes=h,
              densities=rho, num_densities=nden, neighbor=nb)
     return s

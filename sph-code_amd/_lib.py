@@ -52,6 +52,17 @@ SIGNATURES = {
     "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
     "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),
     "sphx_reset_stats": (C.c_int, [_P]),
+    "sphx_set_stream": (C.c_int, [_P, C.c_void_p]),
+    "sphx_reset_stream": (C.c_int, [_P]),
+    "sphx_sync": (C.c_int, [_P]),
+    "sphx_dev_set_mean_h": (C.c_int, [_P, C.c_double]),
+    "sphx_dev_search": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_double, C.c_double, _P]),
+    "sphx_dev_prep": (C.c_int, [_P] + [_P] * 8),
+    "sphx_dev_density": (C.c_int, [_P] + [_P] * 4),
+    "sphx_dev_pi": (C.c_int, [_P] + [_P] * 4),
+    "sphx_dev_visc": (C.c_int, [_P] + [_P] * 4),
+    "sphx_dev_clamp": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "sphx_dev_integrate": (C.c_int, [_P, C.c_int64] + [_P] * 12 + [C.c_double]),
 }
 
 _lib = None

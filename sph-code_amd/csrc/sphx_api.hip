@@ -67,6 +67,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
+    ctx->own_stream = ctx->stream;
     for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
     if (ok) ok = sphx_ensure(ctx, ctx->scal, SC_NSLOTS * 8) == SPHX_OK &&
                  hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess;
@@ -107,7 +108,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     for (int i = 0; i < 10; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -161,6 +162,7 @@ extern "C" int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* poi
     if (n < 1) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld < 1", (long long)n);
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->map_perm = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
     SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->in_b, nb));
@@ -211,6 +213,7 @@ extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const i
     if (f_un_nb && (!f_un || s < 1 || s > SPHX_MAX_SPECIES))
         return sphx_set_err(ctx, SPHX_E_ARG, "species output needs f_un and 1 <= s <= %d", SPHX_MAX_SPECIES);
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->map_perm = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
     SPHX_TRY(upload(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
     SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
@@ -301,6 +304,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
 static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_dt) {
     const int64_t n = ctx->n;
     hipEvent_t* ev = ctx->ev;
+    ctx->map_perm = nullptr;
     HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238
     SPHX_TRY(sphx_clamp(ctx, n, ctx->st));

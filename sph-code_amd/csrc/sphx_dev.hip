@@ -1,0 +1,254 @@
+// sphx_dev.hip - device-pointer building blocks for spatially decomposed (multi-GPU) runs.
+//
+// One rank holds n_total = n_owned + n_ghost particles in the CALLER's order (owned first).
+// The library sorts them by cell internally, searches/sums for the owned ones only, and returns
+// every output in the caller's order.  Between the phases the caller exchanges the ghosts'
+// h_j, rho_j and m Pi_j (8 B each) with their owners over RCCL (sph_code_amd/multigpu.py):
+//   sphx_dev_search -> [halo h] -> sphx_dev_prep -> sphx_dev_density -> [halo rho]
+//   -> sphx_dev_pi -> [halo m Pi] -> sphx_dev_visc -> sphx_dev_integrate
+// All pointers are device pointers; calls are asynchronous on the context's stream except
+// sphx_dev_search, which synchronises once (bounding-box read-back for the cell grid).
+#include "sphx_internal.h"
+#pragma clang fp contract(off)
+#include <float.h>
+
+extern "C" int sphx_set_stream(sphx_ctx* ctx, void* stream) {
+    if (!ctx) return SPHX_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = (hipStream_t)stream;          // NULL is HIP's default (null) stream
+    return SPHX_OK;
+}
+
+extern "C" int sphx_reset_stream(sphx_ctx* ctx) {
+    if (!ctx) return SPHX_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
+    return SPHX_OK;
+}
+
+__global__ __launch_bounds__(256) void gather3_aos_kernel(int n, const int* perm, const double* aos,
+                                                          double* xs, double* ys, double* zs, int* inv) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int p = perm[t];
+    xs[t] = aos[3 * (size_t)p]; ys[t] = aos[3 * (size_t)p + 1]; zs[t] = aos[3 * (size_t)p + 2];
+    inv[p] = t;
+}
+
+// rec[s].<field> = src[perm[s]]  (field given as an offset in doubles inside the 128-B record)
+__global__ __launch_bounds__(256) void inject_field_kernel(int n, const int* perm, const double* src,
+                                                           Rec* rec, int field) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    reinterpret_cast<double*>(&rec[t])[field] = src[perm[t]];
+}
+
+#define NEED(p)                                                                              \
+    do {                                                                                     \
+        if (!(p)) return sphx_set_err(ctx, SPHX_E_ARG, "%s: argument %s is NULL", __func__, #p); \
+    } while (0)
+
+extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, int k, const double* pos,
+                               const double* hint, double rscale, double dist, double* h_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(h_out);
+    if (n_total < 1 || n_total > 0x7FFFFFF0ll || n_owned < 0 || n_owned > n_total)
+        return sphx_set_err(ctx, SPHX_E_ARG, "n_total=%lld n_owned=%lld out of range", (long long)n_total,
+                            (long long)n_owned);
+    if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = n_total;
+    const size_t nb = (size_t)n * sizeof(double);
+    ctx->map_perm = nullptr;
+    DevBuf* bufs[] = {&ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g};
+    for (DevBuf* b : bufs) SPHX_TRY(sphx_ensure(ctx, *b, nb));
+    double *x = ctx->in_b.as<double>(), *y = ctx->in_c.as<double>(), *z = ctx->in_d.as<double>();
+    double *xs = ctx->in_e.as<double>(), *ys = ctx->in_f.as<double>(), *zs = ctx->in_g.as<double>();
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, pos, x, y, z));
+    double cell_hint = 0.0;
+    if (ctx->dev_hmean > 0.0) cell_hint = ctx->cell_factor * ctx->dev_hmean;
+    SPHX_TRY(sphx_build_grid(ctx, n, k, x, y, z, cell_hint));
+    SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
+    hipLaunchKernelGGL(gather3_aos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (int)n, ctx->perm.as<int>(), pos, xs, ys, zs, ctx->inv.as<int>());
+    HIPCHK(hipGetLastError());
+    SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * sphx_pad64(n) * sizeof(int)));
+    ctx->map_perm = ctx->perm.as<int>();
+    ctx->map_nactive = (int)n_owned;
+    ctx->n = n;
+    ctx->npad = sphx_pad64(n);
+    ctx->k = k;
+    KnnOut o;
+    o.nbr = ctx->nbr.as<int>();
+    o.h_sorted = nullptr; o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr;
+    o.h_by_id = h_out;
+    ctx->knn_hint_by_id = (hint != nullptr);
+    int rc = sphx_knn(ctx, n, k, xs, ys, zs, ctx->perm.as<int>(), ctx->inv.as<int>(), hint,
+                      rscale > 0.0 ? rscale : ctx->rscale, dist, o);
+    ctx->knn_hint_by_id = false;
+    return rc;
+}
+
+extern "C" int sphx_dev_set_mean_h(sphx_ctx* ctx, double mean_h) {
+    if (!ctx) return SPHX_E_ARG;
+    ctx->dev_hmean = mean_h;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_prep(sphx_ctx* ctx, const double* pos, const double* vel, const double* mass,
+                             const double* h, const double* T, const double* mu, const double* gamma,
+                             const double* ptype) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel); NEED(mass); NEED(h); NEED(T); NEED(mu); NEED(gamma); NEED(ptype);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_prep before sphx_dev_search");
+    HIPCHK(hipSetDevice(ctx->device));
+    return sphx_prep(ctx, ctx->n, nullptr, nullptr, nullptr, pos, nullptr, nullptr, nullptr, vel, mass, h, T,
+                     mu, gamma, ptype);
+}
+
+static int copy_out(sphx_ctx* ctx, double* dst, const DevBuf& src, size_t bytes) {
+    if (!dst) return SPHX_OK;
+    HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, double* nden,
+                                double* hydro_accel) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_density before sphx_dev_search");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)ctx->n * sizeof(double);
+    SPHX_TRY(sphx_pass_density(ctx, ctx->n, ctx->k));
+    SPHX_TRY(copy_out(ctx, rho, ctx->rho, nb));
+    SPHX_TRY(copy_out(ctx, rho_dust, ctx->rhod, nb));
+    SPHX_TRY(copy_out(ctx, nden, ctx->nden, nb));
+    SPHX_TRY(copy_out(ctx, hydro_accel, ctx->ha, 3 * nb));
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi, double* Bw, double* ct_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(rho_complete);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_pi before sphx_dev_search");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       ctx->map_perm, rho_complete, ctx->rec1.as<Rec>(), 12);
+    HIPCHK(hipGetLastError());
+    SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
+    SPHX_TRY(copy_out(ctx, Pi, ctx->Pi, (size_t)n * sizeof(double)));
+    SPHX_TRY(copy_out(ctx, Bw, ctx->Bw, (size_t)n * sizeof(double)));
+    if (ct_out)   // the positive double whose bits are the minimum (0x7F7F... = none found)
+        HIPCHK(hipMemcpyAsync(ct_out, ctx->scal.as<u64>() + SC_CT_BITS, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const double* mass,
+                             double* visc_accel, double* visc_heat) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(Bw_complete); NEED(mass);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_visc before sphx_dev_search");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       ctx->map_perm, Bw_complete, ctx->rec1.as<Rec>(), 13);
+    HIPCHK(hipGetLastError());
+    SPHX_TRY(sphx_pass_visc(ctx, n, ctx->k, mass));
+    SPHX_TRY(copy_out(ctx, visc_accel, ctx->va, 3 * (size_t)n * sizeof(double)));
+    SPHX_TRY(copy_out(ctx, visc_heat, ctx->vh, (size_t)n * sizeof(double)));
+    return SPHX_OK;
+}
+
+// ---- drv:460-491 on caller-order (n,3) arrays, owned particles only ---------------------------
+__device__ __forceinline__ double nan_to_num_v(double v) {
+    if (v != v) return 0.0;
+    if (v > DBL_MAX) return DBL_MAX;
+    if (v < -DBL_MAX) return -DBL_MAX;
+    return v;
+}
+struct DevIntegArgs {
+    int n;
+    double *pos, *vel, *acc, *E, *T;
+    const double *m, *mu, *gam, *ptype, *ha, *va, *vh;
+    double dt, m_h, kB, lim;
+};
+__global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const double dt = a.dt;
+    const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
+    double v[3], pa[3], vis[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v[c] = a.vel[3 * (size_t)i + c];
+        pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
+        vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
+    }
+    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double an = sqrt(vis[0] * vis[0] + vis[1] * vis[1] + vis[2] * vis[2]);
+    if (vn - an * dt < 0.0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vis[c] = -v[c] / dt;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double tot = pa[c] + vis[c];
+        const double old = a.acc[3 * (size_t)i + c];
+        a.pos[3 * (size_t)i + c] = a.pos[3 * (size_t)i + c] + (tot * (dt * dt)) / 2.0 + v[c] * dt;
+        a.vel[3 * (size_t)i + c] = v[c] + (tot + old) / 2.0 * dt;
+        a.acc[3 * (size_t)i + c] = tot;
+    }
+    const double E = nan_to_num_v(a.E[i]) + nan_to_num_v(a.vh[i] * dt);
+    a.E[i] = E;
+    a.T[i] = nan_to_num_v(E * (a.mu[i] * a.m_h) / (a.gam[i] * a.m[i] * a.kB));
+}
+// drv:233-238 on (n,3) arrays
+__global__ __launch_bounds__(256) void dev_clamp_kernel(int n3, double lim, double* pos, double* vel) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n3) return;
+    double q = pos[e];
+    q = (q > lim) ? lim : q;
+    q = (q < -lim) ? -lim : q;
+    pos[e] = nan_to_num_v(q);
+    vel[e] = nan_to_num_v(vel[e]);
+}
+
+extern "C" int sphx_dev_clamp(sphx_ctx* ctx, int64_t n, double* pos, double* vel) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n < 1) return SPHX_OK;
+    hipLaunchKernelGGL(dev_clamp_kernel, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (int)(3 * n), ctx->cst.pos_clamp, pos, vel);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                                  double* E_internal, double* T, const double* mass, const double* mu,
+                                  const double* gamma, const double* ptype, const double* hydro_accel,
+                                  const double* visc_accel, const double* visc_heat, double dt) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel); NEED(accel_old); NEED(E_internal); NEED(T); NEED(mass); NEED(mu); NEED(gamma);
+    NEED(ptype); NEED(hydro_accel); NEED(visc_accel); NEED(visc_heat);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n_owned < 1) return SPHX_OK;
+    DevIntegArgs a;
+    a.n = (int)n_owned;
+    a.pos = pos; a.vel = vel; a.acc = accel_old; a.E = E_internal; a.T = T;
+    a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
+    a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
+    a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
+    hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+extern "C" int sphx_sync(sphx_ctx* ctx) {
+    if (!ctx) return SPHX_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}

@@ -60,7 +60,10 @@ struct StateArrays {
 
 struct sphx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream every launch goes to (own_stream or the caller's)
+    hipStream_t own_stream = nullptr;
+    double dev_hmean = 0.0;             // device API: mean h of the previous search (cell size)
+    bool knn_hint_by_id = false;        // device API: search-radius hints are in caller order
     char err[512] = {0};
     sphx_constants cst;
     double rscale = 1.12, cell_factor = 0.6;    // search tuning (sphx_set_tuning)
@@ -71,6 +74,8 @@ struct sphx_ctx {
     int k = 0, s = 0;
     DevBuf rec1, recv;            // Rec[n] (recv unused)
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
+    const int* map_perm = nullptr;  // device API: sorted -> caller index (nullptr: identity)
+    int map_nactive = 0;            // device API: callers' particles below this are computed
     DevBuf rho, rhod, nden, G, Pi, Bw, csi, va, vh, ha, F;
     DevBuf relv;                  // per-particle max relative speed^2 (crossing time)
     DevBuf scal;                  // small device scalars: ct bits, dt, counters

@@ -23,12 +23,14 @@
 
 struct KnnArgs {
     int n, k, npad;
+    int n_active;              // queries with id >= n_active (ghosts) are skipped
     const double *x, *y, *z;
     const int* id;
     const int* inv;
     const int* cell_start;
     GridParams g;
     const double* rsearch;
+    int hint_by_id;            // rsearch is indexed by id (caller order) instead of sorted order
     double rscale;
     double rbound;
     int* nbr;
@@ -143,12 +145,16 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
             if (lane < K) tile[lane][li] = -1;
             continue;
         }
+        if (a.id[i] >= a.n_active) {          // wave-uniform: a ghost is a candidate, not a query
+            if (lane < K) tile[lane][li] = -1;
+            continue;
+        }
         const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
         const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
         const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
         const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
 
-        double R = a.rsearch ? a.rsearch[i] * a.rscale : 0.0;
+        double R = a.rsearch ? a.rsearch[a.hint_by_id ? a.id[i] : i] * a.rscale : 0.0;
         if (!(R > 0.0)) {
             // density estimate from the 3x3x3 block of cells around the particle
             int cnt = 0, nc = 0;
@@ -333,11 +339,13 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.n = (int)n;
     a.k = k;
     a.npad = (int)sphx_pad64(n);
+    a.n_active = ctx->map_perm ? ctx->map_nactive : 0x7FFFFFFF;
     a.x = xs; a.y = ys; a.z = zs;
     a.id = id; a.inv = inv;
     a.cell_start = ctx->cell_start.as<int>();
     a.g = ctx->grid;
     a.rsearch = rsearch;
+    a.hint_by_id = ctx->knn_hint_by_id ? 1 : 0;
     a.rscale = rscale;
     a.rbound = (rbound > 0.0) ? rbound : INFINITY;
     a.nbr = out.nbr;

@@ -21,11 +21,13 @@ struct PrepArgs {
     const double *m, *h, *T, *mu, *gam, *ptype;
     double kB, amu;
     Rec* rec;
+    const int* perm;                       // sorted -> caller index of the inputs (nullptr: identity)
 };
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    const int i = a.perm ? a.perm[t] : t;
     const double m = a.m[i], h = a.h[i], T = a.T[i], mu = a.mu[i], gam = a.gam[i], pt = a.ptype[i];
     const double g = (pt == 0.0) ? 1.0 : 0.0;
     Rec r;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     r.Bw = 0.0;
     r.csi = sqrt(gam * a.kB * T / (mu * a.amu) * g);          // nsc:647 own form
     r.h = h;
-    a.rec[i] = r;
+    a.rec[t] = r;
 }
 
 int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
@@ -60,6 +62,7 @@ int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     a.m = m; a.h = h; a.T = T; a.mu = mu; a.gam = gam; a.ptype = ptype;
     a.kB = ctx->cst.k_B; a.amu = ctx->cst.amu;
     a.rec = ctx->rec1.as<Rec>();
+    a.perm = ctx->map_perm;
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -88,6 +91,12 @@ int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_dev) {
     return SPHX_OK;
 }
 
+// Output mapping.  The passes run in cell-sorted order; with a map, sorted particle i is the
+// caller's particle perm[i], only callers' particles below n_active (the rank's OWNED ones, ghosts
+// follow) are computed, and outputs are written in the caller's order.  perm == nullptr: identity.
+struct OutMap { const int* perm; int n_active; };
+__device__ __forceinline__ int out_index(const OutMap& m, int i) { return m.perm ? m.perm[i] : i; }
+
 // 32-B pieces of a record, loaded as two 16-B vectors each
 struct Q4 { double a, b, c, d; };
 __device__ __forceinline__ Q4 load4(const double* p) {
@@ -98,10 +107,13 @@ __device__ __forceinline__ Q4 load4(const double* p) {
 
 // ---- pass 1 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                           Rec* rec, double* rho, double* rhod,
-                                                           double* nden, double* G, double* ha) {
+                                                           Rec* rec, OutMap om, double* rho,
+                                                           double* rhod, double* nden, double* G,
+                                                           double* ha) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int o = out_index(om, i);
+    if (o >= om.n_active) return;
     const double* self = reinterpret_cast<const double*>(&rec[i]);
     const Q4 s0 = load4(self), s1 = load4(self + 4);          // x y z h2 | c1 ms A Nw
     int j0 = nbr[i];
@@ -131,12 +143,12 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
         gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
     }
-    rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+    rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
     rec[i].rho = s_rho;                                       // read by pass 2 (next kernel)
-    G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
-    ha[3 * (size_t)i + 0] = -gx / s_rho;                      // nsc:619
-    ha[3 * (size_t)i + 1] = -gy / s_rho;
-    ha[3 * (size_t)i + 2] = -gz / s_rho;
+    G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
+    ha[3 * (size_t)o + 0] = -gx / s_rho;                      // nsc:619
+    ha[3 * (size_t)o + 1] = -gy / s_rho;
+    ha[3 * (size_t)o + 2] = -gz / s_rho;
 }
 
 int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
@@ -147,6 +159,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
     hipLaunchKernelGGL(pass_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
+                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
                        ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
@@ -169,10 +182,12 @@ __device__ __forceinline__ u64 block_min_u64(u64 v) {
 }
 
 __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                      Rec* rec, double* Pi, u64* ct_bits) {
+                                                      Rec* rec, OutMap om, double* Pi, double* BwOut,
+                                                      u64* ct_bits) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
-    if (i < n) {
+    const int o = (i < n) ? out_index(om, i) : 0x7FFFFFFF;
+    if (i < n && o < om.n_active) {
         const Rec* self = &rec[i];
         int j0 = nbr[i];
         if (j0 < 0) j0 = i;
@@ -197,8 +212,10 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
             s_pi += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;             // nsc:649
             maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);       // nsc:780
         }
-        Pi[i] = s_pi;
-        rec[i].Bw = fmax(ms_i, 0.0) * s_pi;                                 // m Pi [t==0]  nsc:651
+        Pi[o] = s_pi;
+        const double bw = fmax(ms_i, 0.0) * s_pi;                           // m Pi [t==0]  nsc:651
+        rec[i].Bw = bw;
+        if (BwOut) BwOut[o] = bw;
         if (ms_i > 0.0) {                                                   // gas only     nsc:782
             double ct = h_i / sqrt(maxrel);
             if (ct != ct) ct = 0.0;                                         // nan_to_num
@@ -213,22 +230,26 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
 int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double* ptype) {
     (void)ptype; (void)h;
     SPHX_TRY(sphx_ensure(ctx, ctx->Pi, (size_t)n * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
-                       ctx->Pi.as<double>(), ct);
+                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
+                       ctx->Pi.as<double>(), ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
 
 // ---- pass 3 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                        const Rec* __restrict__ rec,
+                                                        const Rec* __restrict__ rec, OutMap om,
                                                         const double* __restrict__ m, double* va,
                                                         double* vh) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int o = out_index(om, i);
+    if (o >= om.n_active) return;
     const Rec* self = &rec[i];
     int j0 = nbr[i];
     if (j0 < 0) j0 = i;
@@ -254,15 +275,16 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         ax += bx; ay += by; az += bz;
         heat += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
     }
-    va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
-    vh[i] = heat * m[i] / 2.0;                                              // nsc:654
+    va[3 * (size_t)o + 0] = -ax; va[3 * (size_t)o + 1] = -ay; va[3 * (size_t)o + 2] = -az;
+    vh[o] = heat * m[o] / 2.0;                                              // nsc:654  (m in output order)
 }
 
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->va, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(), m,
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
+                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
                        ctx->va.as<double>(), ctx->vh.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;

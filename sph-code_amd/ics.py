@@ -22,9 +22,19 @@ GAMMA_SPECIE = np.array([7. / 5, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3,
 F_GAS = np.array([.86, .14] + [0.] * 13)
 
 
-def _finish(pts, vel, mass, T, ptype=None, f_un=None):
+def _finish(pts, vel, mass, T, ptype=None, f_un=None, light=False):
+    """light=True: do not materialise the (N,15) composition (all-gas ICs of many millions of
+    particles); mu/gamma are the same expressions evaluated on the single composition row."""
     n = len(pts)
     ptype = np.zeros(n) if ptype is None else ptype
+    if f_un is None and light:
+        row = F_GAS[None, :]
+        mu = np.full(n, (np.sum(row * MU_SPECIE, axis=1) / np.sum(row, axis=1))[0])
+        gam = np.full(n, (np.sum(row * GAMMA_SPECIE, axis=1) / np.sum(row, axis=1))[0])
+        E = gam * mass * K_B * T / (mu * M_H)
+        return dict(points=np.ascontiguousarray(pts), velocities=np.ascontiguousarray(vel), mass=mass,
+                    particle_type=ptype, f_un=None, T=T, mu_array=mu, gamma_array=gam, E_internal=E,
+                    total_accel=np.zeros((n, 3)))
     if f_un is None:
         f_un = np.tile(F_GAS, (n, 1))
     mu = np.sum(f_un * MU_SPECIE, axis=1) / np.sum(f_un, axis=1)        # drv:162
@@ -40,17 +50,17 @@ def _unit_vectors(rs, n):
     return u / np.linalg.norm(u, axis=1)[:, None]
 
 
-def uniform_sphere(n, seed=12346, radius=0.625e6 * AU, sigma_v=1000.):
+def uniform_sphere(n, seed=12346, radius=0.625e6 * AU, sigma_v=1000., light=False):
     """C1."""
     rs = np.random.RandomState(seed)
     pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * radius
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
-    return _finish(pts, vel, mass, T)
+    return _finish(pts, vel, mass, T, light=light)
 
 
-def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000.):
+def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000., light=False):
     """C2: radii by inverse CDF of M(<r) ~ int r^2/((r/a)^4+1) dr on the reference's radial grid
     r = sqrt(linspace(0, 25e14, 2001)) AU (imf/lane_emden_modified.py:317-343)."""
     rs = np.random.RandomState(seed)
@@ -65,10 +75,10 @@ def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000.):
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
-    return _finish(pts, vel, mass, T)
+    return _finish(pts, vel, mass, T, light=light)
 
 
-def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.28 * SOLAR):
+def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.28 * SOLAR, light=False):
     """C3: cold uniform gas; the innermost `kick_mass` of gas receives 73.6 % of `energy` as a
     radial kick and 26.4 % as heat."""
     rs = np.random.RandomState(seed)
@@ -85,7 +95,7 @@ def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.
     vk = np.sqrt(2. * ek / np.sum(mass[inner]))
     rhat = pts[inner] / np.maximum(r[inner], 1e-300)[:, None]
     vel[inner] += vk * rhat
-    st = _finish(pts, vel, mass, T)
+    st = _finish(pts, vel, mass, T, light=light)
     eth = 0.264 * energy / nk
     st["E_internal"][inner] += eth
     st["T"][inner] = st["E_internal"][inner] * (st["mu_array"][inner] * M_H) / \
@@ -93,14 +103,14 @@ def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.
     return st
 
 
-def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000.):
+def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000., light=False):
     """C4: the reference's own IC (sph/code_running.py:62,132)."""
     rs = np.random.RandomState(seed)
     pts = (rs.rand(n, 3) - 0.5) * side
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
-    return _finish(pts, vel, mass, T)
+    return _finish(pts, vel, mass, T, light=light)
 
 
 def cfl_dt(state, k=40, courant=0.25):

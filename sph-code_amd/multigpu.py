@@ -1,0 +1,479 @@
+"""Spatial domain decomposition of the SPH hot path over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm).  The
+reference has no distributed code at all (only SLURM replicas), so this is new
+design, following SURVEY.md 8(e):
+
+  * recursive coordinate bisection of the particle set into `world` axis-aligned regions with
+    equal counts; a particle is OWNED by the rank whose region contains it;
+  * per step, each rank imports GHOST copies of the foreign particles lying within its halo
+    width (>= the largest kNN radius among its owned particles) of its region, searches / sums
+    over owned+ghost candidates for its owned particles only, and refreshes the ghosts' h_j,
+    rho_j and m*Pi_j from their owners between the passes (the kernel uses the NEIGHBOUR's h
+    (nsc:587-588), rho (nsc:646) and Pi (nsc:651)) - four point-to-point halo phases;
+  * exchange = grouped isend/irecv between the (at most world-1) peers that share a halo, no
+    collective on the data path; the only collectives are two scalars per step (halo widths:
+    all_gather of one double; dt: all_reduce(min) of the crossing time, nsc:786);
+  * after the leapfrog update particles that left their region migrate to the new owner.
+
+The halo width is verified after every search (all owned h_i <= width, otherwise the step's
+exchange is redone with a wider halo), so the decomposed result equals the single-GPU result.
+
+Compute is injected through a small backend interface; the product backend `LibBackend` calls
+libsphx.so's sphx_dev_* entry points on the rank's GPU (no CPU fallback).
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HUGE_CT = float(np.frombuffer(np.array([0x7F7F7F7F7F7F7F7F], dtype=np.uint64).tobytes(), dtype=np.float64)[0])
+
+
+# ==============================================================================================
+# decomposition
+# ==============================================================================================
+def rcb_regions(points, world):
+    """Recursive coordinate bisection -> (owner (N,) int64, lo (world,3), hi (world,3)).
+    Regions tile all of space (outer faces at -inf/+inf); counts differ by at most 1 per cut."""
+    pts = np.asarray(points, dtype=np.float64)
+    n = len(pts)
+    owner = np.zeros(n, np.int64)
+    lo = np.full((world, 3), -np.inf)
+    hi = np.full((world, 3), np.inf)
+
+    def split(idx, r0, r1, blo, bhi):
+        nr = r1 - r0
+        if nr == 1:
+            owner[idx] = r0
+            lo[r0], hi[r0] = blo, bhi
+            return
+        nl = nr // 2
+        sub = pts[idx]
+        ext = sub.max(axis=0) - sub.min(axis=0) if len(idx) else np.zeros(3)
+        ax = int(np.argmax(ext))
+        kcut = int(round(len(idx) * nl / nr))
+        kcut = min(max(kcut, 1), max(len(idx) - 1, 1))
+        order = np.argpartition(sub[:, ax], kcut - 1) if len(idx) > 1 else np.arange(len(idx))
+        left_vals = sub[order[:kcut], ax]
+        right_vals = sub[order[kcut:], ax]
+        cut = 0.5 * (left_vals.max() + right_vals.min()) if len(right_vals) and len(left_vals) else 0.0
+        lhi = np.array(bhi); lhi[ax] = cut
+        rlo = np.array(blo); rlo[ax] = cut
+        split(idx[order[:kcut]], r0, r0 + nl, np.array(blo), lhi)
+        split(idx[order[kcut:]], r0 + nl, r1, rlo, np.array(bhi))
+
+    split(np.arange(n), 0, world, np.full(3, -np.inf), np.full(3, np.inf))
+    return owner, lo, hi
+
+
+def region_of(pos, lo, hi):
+    """Owner rank of each position (torch (n,3)); regions tile space, ties go to the lower rank."""
+    inside = ((pos[:, None, :] >= lo[None]) & (pos[:, None, :] <= hi[None])).all(dim=2)   # (n, world)
+    return torch.argmax(inside.to(torch.int8), dim=1)
+
+
+def dist_to_region(pos, lo, hi):
+    """Euclidean distance from each position (n,3) to the box [lo,hi] (infinite faces count 0)."""
+    d = torch.clamp(lo[None] - pos, min=0.) + torch.clamp(pos - hi[None], min=0.)
+    d = torch.nan_to_num(d, nan=0.0, posinf=0.0, neginf=0.0)
+    return torch.sqrt((d * d).sum(dim=1))
+
+
+# ==============================================================================================
+# point-to-point halo exchange
+# ==============================================================================================
+class Exchanger:
+    """Variable-size row exchange between all ranks with grouped isend/irecv."""
+
+    def __init__(self, rank, world, comm_device):
+        self.rank, self.world, self.comm_device = rank, world, comm_device
+        self.bytes_sent = 0
+
+    def counts(self, send_counts):
+        """send_counts (world,) -> recv_counts (world,) (what each peer will send to me)."""
+        if self.world == 1:
+            return [0]
+        mine = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_device)
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine)
+        return [int(allc[p][self.rank]) for p in range(self.world)]
+
+    def rows(self, send_bufs, recv_counts, width, dtype=torch.float64):
+        """send_bufs[p]: (count_p, width) tensor for peer p (any device) -> list of received
+        (recv_counts[p], width) tensors on the compute device of send_bufs."""
+        out = [None] * self.world
+        if self.world == 1:
+            return out
+        ops, stage = [], []
+        dev = None
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            sb = send_bufs[p]
+            dev = sb.device if dev is None else dev
+            if sb.shape[0] > 0:
+                t = sb.contiguous().to(self.comm_device)
+                self.bytes_sent += t.numel() * t.element_size()
+                ops.append(dist.P2POp(dist.isend, t, p))
+                stage.append(t)
+            if recv_counts[p] > 0:
+                r = torch.empty((recv_counts[p], width), dtype=dtype, device=self.comm_device)
+                ops.append(dist.P2POp(dist.irecv, r, p))
+                out[p] = r
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for p in range(self.world):
+            if out[p] is not None and dev is not None and out[p].device != dev:
+                out[p] = out[p].to(dev)
+        return out
+
+
+# ==============================================================================================
+# compute backend on the GPU: libsphx sphx_dev_* (include/sphx.h)
+# ==============================================================================================
+class LibBackend:
+    def __init__(self, device_index, k=40, dist_bound=0.0):
+        from . import _lib
+        self.ctx = _lib.Context(device_index)
+        self.lib = self.ctx.lib
+        self.k = k
+        self.dist_bound = dist_bound
+        self.device = torch.device("cuda", device_index)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx.check(self.lib.sphx_set_stream(self.ctx.h, C.c_void_p(stream)))
+        self.n_total = 0
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _chk(self, rc):
+        self.ctx.check(rc)
+
+    def clamp(self, pos, vel):
+        self._chk(self.lib.sphx_dev_clamp(self.ctx.h, pos.shape[0], self._p(pos), self._p(vel)))
+
+    def search(self, pos, n_owned, hint, mean_h):
+        n = pos.shape[0]
+        self.n_total = n
+        h = torch.zeros(n, dtype=torch.float64, device=pos.device)
+        self._chk(self.lib.sphx_dev_set_mean_h(self.ctx.h, float(mean_h)))
+        self._chk(self.lib.sphx_dev_search(self.ctx.h, n, n_owned, self.k, self._p(pos), self._p(hint), 0.0,
+                                           float(self.dist_bound), self._p(h)))
+        return h
+
+    def prep(self, pos, vel, m, h, T, mu, gam, ptype):
+        self._keep = (pos, vel, m, h, T, mu, gam, ptype)
+        self._chk(self.lib.sphx_dev_prep(self.ctx.h, *[self._p(t) for t in self._keep]))
+
+    def density(self):
+        n, dev = self.n_total, self.device
+        rho = torch.zeros(n, dtype=torch.float64, device=dev)
+        nden = torch.zeros(n, dtype=torch.float64, device=dev)
+        ha = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        self._chk(self.lib.sphx_dev_density(self.ctx.h, self._p(rho), None, self._p(nden), self._p(ha)))
+        return rho, nden, ha
+
+    def pi(self, rho_complete):
+        n, dev = self.n_total, self.device
+        bw = torch.zeros(n, dtype=torch.float64, device=dev)
+        ct = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._chk(self.lib.sphx_dev_pi(self.ctx.h, self._p(rho_complete), None, self._p(bw), self._p(ct)))
+        return bw, ct
+
+    def visc(self, bw_complete, m):
+        n, dev = self.n_total, self.device
+        va = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        vh = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._chk(self.lib.sphx_dev_visc(self.ctx.h, self._p(bw_complete), self._p(m), self._p(va), self._p(vh)))
+        return va, vh
+
+    def integrate(self, n_owned, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
+        self._chk(self.lib.sphx_dev_integrate(self.ctx.h, n_owned, self._p(pos), self._p(vel), self._p(acc),
+                                              self._p(E), self._p(T), self._p(m), self._p(mu), self._p(gam),
+                                              self._p(ptype), self._p(ha), self._p(va), self._p(vh), float(dt)))
+
+
+# ==============================================================================================
+# the decomposed step loop
+# ==============================================================================================
+GHOST_FIELDS = ("vel", "m", "T", "mu", "gam", "ptype", "h")      # + pos; sent in halo phase 1
+OWNED_FIELDS = ("pos", "vel", "acc", "m", "T", "mu", "gam", "ptype", "E", "h", "gid")
+
+
+class DistributedSim:
+    """Owned particles of one rank + the per-step halo protocol.  `state` holds this rank's
+    owned particles (reference array conventions, sph/code_running.py:114-177) plus 'gid'
+    (global particle ids); `lo`/`hi` are the (world,3) region boxes of rcb_regions."""
+
+    DT_0 = 60. * 60. * 24. * 365. * 250000.      # nsc:38
+    MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
+
+    def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
+                 halo_scale=1.15):
+        self.rank, self.world, self.backend = rank, world, backend
+        self.device = torch.device(device)
+        self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
+        self.ex = Exchanger(rank, world, self.comm_device)
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        self.s = dict(pos=f(state["points"]), vel=f(state["velocities"]), m=f(state["mass"]), T=f(state["T"]),
+                      mu=f(state["mu_array"]), gam=f(state["gamma_array"]), ptype=f(state["particle_type"]),
+                      E=f(state["E_internal"]))
+        n = self.s["pos"].shape[0]
+        acc = state.get("total_accel")
+        self.s["acc"] = f(acc) if acc is not None else torch.zeros((n, 3), dtype=torch.float64, device=self.device)
+        self.s["h"] = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.s["gid"] = torch.as_tensor(np.asarray(state["gid"], dtype=np.int64)).to(self.device)
+        self.lo = torch.as_tensor(lo, dtype=torch.float64).to(self.device)
+        self.hi = torch.as_tensor(hi, dtype=torch.float64).to(self.device)
+        self.halo_scale = halo_scale
+        self.first = True
+        self.dt_last = 0.0
+        self.last = {}
+        self.stats = dict(steps=0, ghosts=0, redo=0, migrated=0)
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def n_owned(self):
+        return self.s["pos"].shape[0]
+
+    def _allgather_scalar(self, v):
+        if self.world == 1:
+            return [float(v)]
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.comm_device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [float(o[0]) for o in out]
+
+    def _allreduce_min(self, v):
+        if self.world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t[0])
+
+    def _allreduce_max(self, v):
+        if self.world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def _plan(self, widths):
+        """Send lists: my owned particles within widths[p] of region p."""
+        pos = self.s["pos"]
+        send_idx = []
+        for p in range(self.world):
+            if p == self.rank:
+                send_idx.append(None)
+                continue
+            d = dist_to_region(pos, self.lo[p], self.hi[p])
+            send_idx.append(torch.nonzero(d <= widths[p]).flatten())
+        counts = [0 if ix is None else int(ix.numel()) for ix in send_idx]
+        recv_counts = self.ex.counts(counts)
+        return send_idx, recv_counts
+
+    def _halo(self, send_idx, recv_counts, owned_rows):
+        """owned_rows (n_owned, w) -> ghost rows (n_ghost, w), ghosts ordered by source rank."""
+        w = owned_rows.shape[1]
+        bufs = [None if ix is None else owned_rows[ix] for ix in send_idx]
+        got = self.ex.rows(bufs, recv_counts, w)
+        parts = [g for g in got if g is not None]
+        if parts:
+            return torch.cat(parts, dim=0)
+        return torch.zeros((0, w), dtype=torch.float64, device=owned_rows.device)
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, fixed_dt=0.0):
+        s, be, no = self.s, self.backend, self.n_owned
+        be.clamp(s["pos"], s["vel"])                                        # drv:233-238
+        if self.first or float(s["h"].max()) <= 0.0:
+            # bootstrap: a search without ghosts over-estimates every h (fewer candidates), so its
+            # maximum is a rigorous halo width for the first exchange
+            hloc = be.search(s["pos"], no, None, 0.0)
+            my_w = float(hloc[:no].max()) if no else 0.0
+            hint_owned = None
+            mean_h = float(hloc[:no].mean()) if no else 0.0
+        else:
+            my_w = self.halo_scale * float(s["h"].max())
+            hint_owned = s["h"]
+            mean_h = float(s["h"].mean())
+        while True:
+            widths = self._allgather_scalar(my_w)
+            send_idx, recv_counts = self._plan(widths)
+            ng = sum(recv_counts)
+            # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
+            owned_rows = torch.cat([s["pos"], s["vel"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
+                                    s["gam"][:, None], s["ptype"][:, None], s["h"][:, None]], dim=1)
+            g = self._halo(send_idx, recv_counts, owned_rows)
+            pos = torch.cat([s["pos"], g[:, 0:3]], dim=0).contiguous()
+            vel = torch.cat([s["vel"], g[:, 3:6]], dim=0).contiguous()
+            cat1 = lambda own, col: torch.cat([own, g[:, col]], dim=0).contiguous()
+            m, T, mu = cat1(s["m"], 6), cat1(s["T"], 7), cat1(s["mu"], 8)
+            gam, ptype = cat1(s["gam"], 9), cat1(s["ptype"], 10)
+            hint = None if hint_owned is None else cat1(hint_owned, 11)
+            h = be.search(pos, no, hint, mean_h)
+            hmax = float(h[:no].max()) if no else 0.0
+            ok_local = 1.0 if hmax <= my_w else 0.0
+            if self._allreduce_min(ok_local) > 0.5:
+                break
+            if hmax > my_w:                       # a kNN radius outgrew the halo: widen and redo
+                my_w = 1.5 * hmax
+            self.stats["redo"] += 1
+        # ---- halo phase 2: ghosts' h_j ----------------------------------------------------------
+        gh = self._halo(send_idx, recv_counts, h[:no, None])
+        h = torch.cat([h[:no], gh[:, 0]], dim=0).contiguous()
+        be.prep(pos, vel, m, h, T, mu, gam, ptype)
+        rho, nden, ha = be.density()
+        # ---- halo phase 3: ghosts' rho_j --------------------------------------------------------
+        gr = self._halo(send_idx, recv_counts, rho[:no, None])
+        rho = torch.cat([rho[:no], gr[:, 0]], dim=0).contiguous()
+        bw, ct = be.pi(rho)
+        # ---- halo phase 4: ghosts' m Pi_j -------------------------------------------------------
+        gb = self._halo(send_idx, recv_counts, bw[:no, None])
+        bw = torch.cat([bw[:no], gb[:, 0]], dim=0).contiguous()
+        va, vh = be.visc(bw, m)
+        # ---- dt: global minimum crossing time (nsc:786, drv:222-229) ----------------------------
+        ct_local = float(ct.reshape(-1)[0]) if torch.is_tensor(ct) else float(ct)
+        ct_min = self._allreduce_min(ct_local)
+        ctv = self.DT_0 / 10. if ct_min >= HUGE_CT else ct_min + 0.0001
+        if fixed_dt > 0:
+            dt = fixed_dt
+        else:
+            dt = self.DT_0 / 10. if self.first else max(self.DT_0 / 5., min(self.DT_0 * 2., ctv))
+            if ctv > self.MAX_AGE:
+                dt = self.MAX_AGE / 100.
+        be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
+                     ha, va, vh, dt)
+        s["h"] = h[:no].contiguous()
+        self.last = dict(rho=rho[:no], nden=nden[:no], visc_heat=vh[:no])
+        self.dt_last = dt
+        self.first = False
+        self.stats["steps"] += 1
+        self.stats["ghosts"] += ng
+        self._migrate()
+
+    # ------------------------------------------------------------------------------------------
+    def _migrate(self):
+        """Particles that left the region move to their new owner (all owned fields)."""
+        if self.world == 1:
+            return
+        s = self.s
+        owner = region_of(s["pos"], self.lo, self.hi)
+        stay = owner == self.rank
+        send_idx = [None if p == self.rank else torch.nonzero(owner == p).flatten() for p in range(self.world)]
+        counts = [0 if ix is None else int(ix.numel()) for ix in send_idx]
+        recv_counts = self.ex.counts(counts)
+        extra = [self.last[k_][:, None] for k_ in ("rho", "nden", "visc_heat")]
+        rows = torch.cat([s["pos"], s["vel"], s["acc"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
+                          s["gam"][:, None], s["ptype"][:, None], s["E"][:, None], s["h"][:, None],
+                          s["gid"].to(torch.float64)[:, None]] + extra, dim=1)
+        got = self._halo(send_idx, recv_counts, rows)
+        keep = rows[stay]
+        allr = torch.cat([keep, got], dim=0) if got.shape[0] else keep
+        self.stats["migrated"] += int(got.shape[0])
+        s["pos"], s["vel"], s["acc"] = (allr[:, 0:3].contiguous(), allr[:, 3:6].contiguous(),
+                                        allr[:, 6:9].contiguous())
+        for i, nm in enumerate(("m", "T", "mu", "gam", "ptype", "E", "h")):
+            s[nm] = allr[:, 9 + i].contiguous()
+        s["gid"] = allr[:, 16].round().to(torch.int64)
+        self.last = dict(rho=allr[:, 17].contiguous(), nden=allr[:, 18].contiguous(),
+                         visc_heat=allr[:, 19].contiguous())
+
+    def owned_numpy(self):
+        """This rank's owned particles as NumPy arrays keyed like the single-GPU download."""
+        s = self.s
+        c = lambda t: t.detach().cpu().numpy()
+        out = dict(gid=c(s["gid"]), points=c(s["pos"]), velocities=c(s["vel"]), total_accel=c(s["acc"]),
+                   E_internal=c(s["E"]), T=c(s["T"]), sizes=c(s["h"]), dt=self.dt_last)
+        if self.last:
+            out.update(densities=c(self.last["rho"]), num_densities=c(self.last["nden"]),
+                       visc_heat=c(self.last["visc_heat"]))
+        return out
+
+
+def decompose_state(state, world, rank):
+    """Global state dict -> (this rank's owned state incl. 'gid', lo, hi)."""
+    owner, lo, hi = rcb_regions(state["points"], world)
+    sel = np.nonzero(owner == rank)[0]
+    mine = {}
+    for key in ("points", "velocities", "mass", "particle_type", "T", "mu_array", "gamma_array", "E_internal",
+                "total_accel"):
+        mine[key] = np.ascontiguousarray(state[key][sel])
+    mine["gid"] = sel.astype(np.int64)
+    return mine, lo, hi
+
+
+# ==============================================================================================
+# bench leg for N > 1 (called by bench.py under torch.distributed.run)
+# ==============================================================================================
+def bench_main(args, rank, local_rank, world):
+    from . import ics
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs GPUs (libsphx has no CPU path)")
+    # SPHX_DIST_BACKEND=gloo rehearses the launch path with several ranks sharing one GPU (the
+    # halo then travels through host memory); the default is RCCL over xGMI, one GPU per rank.
+    backend = os.environ.get("SPHX_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        comm_dev = dev
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        comm_dev = torch.device("cpu")
+    n_global = args.n * world                       # weak scaling: fixed particles per GPU
+    state = ics.WORKLOADS[args.workload](n_global, light=True)
+    mine, lo, hi = decompose_state(state, world, rank)
+    del state
+    be = LibBackend(dev_index, k=args.k)
+    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev)
+    for _ in range(args.warmup):
+        sim.step()
+    sim.ex.bytes_sent = 0
+    sim.stats.update(ghosts=0, redo=0, migrated=0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    cnt = torch.tensor([float(sim.n_owned), float(sim.stats["ghosts"]) / max(args.steps, 1),
+                        float(sim.ex.bytes_sent) / max(args.steps, 1), float(sim.stats["redo"])],
+                       dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        t = float(tmax[0])
+        total = float(cnt[0])
+        value = total * args.steps / t
+        out = {
+            "metric": "particle-steps/sec + achieved HBM GB/s, 10^6-particle 3D sphere, 1/2/4/8 GPUs",
+            "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s sphere, N=%d (%d per GPU), K=%d, fp64, poly6 kernel, viscosity on"
+                                   % (args.workload, int(total), args.n, args.k),
+                       "particles_per_gpu": args.n,
+                       "decomposition": "recursive coordinate bisection, %d regions, 4-phase p2p halo" % world,
+                       "backend": backend},
+            "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
+                     "search_redos": float(cnt[3])},
+            "step_model": {"algorithmic_bytes_per_particle_step": 1248,
+                           "achieved_GBs": 1248 * value / 1e9,
+                           "frac_of_hbm_peak": 1248 * value / 1e9 / (8000.0 * world)},
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,177 @@
+"""The N > 1 path on CPU: recursive-bisection decomposition, 4-phase point-to-point halo
+exchange, global dt and migration (sph_code_amd/multigpu.py) run with world_size 2 over gloo.
+Compute is played by the CPU oracle (the checker), so what is tested here is the host logic:
+the decomposed step must reproduce the single-domain oracle step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+K = 16
+
+
+class OracleBackend:
+    """Test-only stand-in for multigpu.LibBackend built on the oracle's phase hooks."""
+
+    def __init__(self, k):
+        from oracle import sph_oracle as orc
+        self.orc, self.k = orc, k
+
+    def clamp(self, pos, vel):
+        p, v = self.orc.clamp_state(pos.numpy(), vel.numpy())
+        pos.copy_(torch.from_numpy(p)); vel.copy_(torch.from_numpy(v))
+
+    def search(self, pos, n_owned, hint, mean_h):
+        nb, _, _, _, h = self.orc.neighbors(pos.numpy(), np.inf, self.k, eps=0.0)
+        self.nb, self.no = nb, n_owned
+        return torch.from_numpy(h.copy())
+
+    def prep(self, pos, vel, m, h, T, mu, gam, ptype):
+        self.a = [t.numpy() for t in (pos, vel, m, h, T, mu, gam, ptype)]
+
+    def _hu(self, **kw):
+        pos, vel, m, h, T, mu, gam, ptype = self.a
+        return self.orc.hydro_update(self.nb, pos, m, h, np.ones((len(pos), 1)), ptype, T, mu, gam, vel, **kw)
+
+    def density(self):
+        out = self._hu()
+        return torch.from_numpy(out[3].copy()), torch.from_numpy(out[4].copy()), torch.from_numpy(out[0].copy())
+
+    def pi(self, rho_complete):
+        self.rho_c = rho_complete.numpy()
+        out, inter = self._hu(rho_in=self.rho_c, return_intermediates=True)
+        pos, vel, m, h, T, mu, gam, ptype = self.a
+        pt = ptype.copy(); pt[self.no:] = 1.0                    # ghosts do not vote on dt
+        ct = self.orc.crossing_time(self.nb, vel, h, pt)
+        from sph_code_amd.multigpu import HUGE_CT
+        ctv = HUGE_CT if ct == self.orc.DT_0 / 10. else ct - 0.0001
+        return torch.from_numpy(inter["Bw"].copy()), ctv
+
+    def visc(self, bw_complete, m):
+        out = self._hu(rho_in=self.rho_c, Bj_in=bw_complete.numpy())
+        return torch.from_numpy(out[1].copy()), torch.from_numpy(out[2].copy())
+
+    def integrate(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
+        n = lambda t: t.numpy()[:no]
+        p, v, tot, En, Tn = self.orc.integrate(n(pos), n(vel), n(acc), n(E), n(m), n(mu), n(gam), n(ptype),
+                                               n(ha), n(va), n(vh), dt)
+        for dst, src in ((pos, p), (vel, v), (acc, tot), (E, En), (T, Tn)):
+            dst[:no] = torch.from_numpy(np.ascontiguousarray(src))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, nsteps, workload, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sph_code_amd.ics as ics
+    from sph_code_amd import multigpu as mg
+    state = ics.WORKLOADS[workload](n, light=True)
+    mine, lo, hi = mg.decompose_state(state, world, rank)
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu")
+    for _ in range(nsteps):
+        sim.step()
+    res = sim.owned_numpy()
+    res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(world, n, nsteps, workload, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, nsteps, workload, str(tmp_path)), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    gid = np.concatenate([p["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(n)), "particles lost or duplicated"
+    order = np.argsort(gid)
+    merged = {k_: np.concatenate([p[k_] for p in parts])[order]
+              for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities")}
+    merged["dt"] = [float(p["dt"]) for p in parts]
+    merged["stats"] = np.sum([p["stats"] for p in parts], axis=0)
+    return merged
+
+
+def _reference(n, nsteps, workload):
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    s = ics.WORKLOADS[workload](n, light=True)
+    for it in range(nsteps):
+        s = orc.step(s, n_neigh=K, eps=0.0, first=(it == 0))
+    return s
+
+
+def test_rcb_regions_balanced_and_tiling():
+    from sph_code_amd import multigpu as mg
+    rs = np.random.RandomState(3)
+    pts = rs.normal(size=(5000, 3)) * np.array([3., 1., 2.])
+    for world in (1, 2, 3, 4, 8):
+        owner, lo, hi = mg.rcb_regions(pts, world)
+        cnt = np.bincount(owner, minlength=world)
+        assert cnt.sum() == 5000 and cnt.max() - cnt.min() <= world
+        back = mg.region_of(torch.from_numpy(pts), torch.from_numpy(lo), torch.from_numpy(hi)).numpy()
+        assert np.array_equal(back, owner)
+        probe = rs.normal(size=(2000, 3)) * 50.
+        inside = ((probe[:, None, :] >= lo[None]) & (probe[:, None, :] <= hi[None])).all(axis=2)
+        assert (inside.sum(axis=1) >= 1).all()                    # regions tile space
+        d = mg.dist_to_region(torch.from_numpy(pts), torch.from_numpy(lo[0]), torch.from_numpy(hi[0])).numpy()
+        assert (d[owner == 0] == 0).all() and (d >= 0).all()
+
+
+def test_world1_matches_oracle_step():
+    """DistributedSim with one rank (no communication) == the oracle's single-domain step."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd import multigpu as mg
+    n, nsteps = 1500, 3
+    state = ics.uniform_sphere(n, light=True)
+    mine, lo, hi = mg.decompose_state(state, 1, 0)
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), 0, 1, device="cpu")
+    for _ in range(nsteps):
+        sim.step()
+    got = sim.owned_numpy()
+    ref = _reference(n, nsteps, "uniform_sphere")
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
+    np.testing.assert_allclose(got["velocities"], ref["velocities"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+    assert got["dt"] == pytest.approx(ref["dt"], rel=1e-14)
+
+
+@pytest.mark.parametrize("workload", ["uniform_sphere", "polytrope"])
+def test_world2_gloo_matches_single_domain(workload, tmp_path):
+    """world_size 2 over gloo: halo exchange + global dt + migration reproduce the single-domain
+    result (same neighbour sets in the same order -> same sums)."""
+    n, nsteps = 3000, 3
+    got = _run_world(2, n, nsteps, workload, tmp_path)
+    ref = _reference(n, nsteps, workload)
+    assert got["dt"][0] == got["dt"][1] == pytest.approx(ref["dt"], rel=1e-14)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
+    np.testing.assert_allclose(got["velocities"], ref["velocities"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-12)
+    ghosts, redo, migrated, sent = got["stats"]
+    assert ghosts > 0 and sent > 0                                # the halo really was exchanged
+
+
+def test_world4_gloo_runs(tmp_path):
+    n, nsteps = 2400, 2
+    got = _run_world(4, n, nsteps, "uniform_sphere", tmp_path)
+    ref = _reference(n, nsteps, "uniform_sphere")
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
