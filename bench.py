@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path (cell sort -> exact kNN -> density / pressure-gradient /
 viscosity sums -> dt -> leapfrog) over the whole particle set, state resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES] [--workload NAME]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles PER_GPU] [--workload NAME]
 
 N > 1 is launched by torch.distributed.run (one rank per GPU); see sph_code_amd/multigpu.py.
 Prints ONE JSON line on rank 0.
@@ -47,10 +47,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="particles per GPU")
+    ap.add_argument("--particles", dest="n", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--workload", default="polytrope")
-    ap.add_argument("--k", type=int, default=40)
-    ap.add_argument("--cpu-n", type=int, default=100_000)
+    ap.add_argument("--neigh", dest="k", type=int, default=40, help="N_NEIGH")
+    ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=400_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
