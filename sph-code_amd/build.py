@@ -31,8 +31,9 @@ def build(force=False, verbose=False):
     """Compile every HIP source into sph-code_amd/libsphx.so.  Returns the library path."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("SPHX_EXTRA_FLAGS", "").split()
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + \
+          ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -37,12 +37,12 @@ __global__ __launch_bounds__(256) void gather3_aos_kernel(int n, const int* perm
     inv[p] = t;
 }
 
-// rec[s].<field> = src[perm[s]]  (field given as an offset in doubles inside the 128-B record)
+// dst[s * stride] = src[perm[s]]: caller-order values into a sorted-order compact array
 __global__ __launch_bounds__(256) void inject_field_kernel(int n, const int* perm, const double* src,
-                                                           Rec* rec, int field) {
+                                                           double* dst, int stride) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    reinterpret_cast<double*>(&rec[t])[field] = src[perm[t]];
+    dst[(size_t)t * stride] = src[perm[t]];
 }
 
 #define NEED(p)                                                                              \
@@ -135,7 +135,7 @@ extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = ctx->n;
     hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->map_perm, rho_complete, ctx->rec1.as<Rec>(), 12);
+                       ctx->map_perm, rho_complete, ctx->rho_s.as<double>(), 1);
     HIPCHK(hipGetLastError());
     SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
     SPHX_TRY(copy_out(ctx, Pi, ctx->Pi, (size_t)n * sizeof(double)));
@@ -153,7 +153,7 @@ extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const dou
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = ctx->n;
     hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->map_perm, Bw_complete, ctx->rec1.as<Rec>(), 13);
+                       ctx->map_perm, Bw_complete, ctx->bc_s.as<double>(), 2);
     HIPCHK(hipGetLastError());
     SPHX_TRY(sphx_pass_visc(ctx, n, ctx->k, mass));
     SPHX_TRY(copy_out(ctx, visc_accel, ctx->va, 3 * (size_t)n * sizeof(double)));

@@ -170,6 +170,21 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
     perm[slot] = i;
 }
 
+// The atomic scatter fills a cell in arrival order; sorting each cell's slice by the particles'
+// previous index makes the cell-sorted order (and everything derived from it: tie-breaks in the
+// search, summation order) identical from run to run.  Cells hold a few particles each.
+__global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* cell_start, int* perm) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    const int s = cell_start[c], e = cell_start[c + 1];
+    for (int i = s + 1; i < e; ++i) {
+        const int v = perm[i];
+        int j = i - 1;
+        while (j >= s && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+        perm[j + 1] = v;
+    }
+}
+
 #define SPHX_MAX_CELLS (SCAN_TILE * 4096)
 
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
@@ -230,6 +245,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>());
+    hipLaunchKernelGGL(cell_sort_members, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, nc, start,
+                       ctx->perm.as<int>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -22,24 +22,33 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-// Gather record of one particle: ONE 128-B cache line holds everything any pass reads of a
-// neighbour, so each (particle, neighbour) pair touches exactly one line per pass.
-//   pass 1 reads [0..7]; pass 2 reads [0..3] + [8..12]; pass 3 reads [0..4] + [8..10] + [13].
-// rho / Bw are written by the owner's thread in pass 1 / pass 2 and read by others only in
-// the following kernel.
-struct __attribute__((aligned(128))) Rec {
+// Gather records.  What limits the sum passes is the number of distinct cache lines a
+// (particle, neighbour) pair touches, so each pass gets ONE dense 64-B record per neighbour
+// (two particles per 128-B line: cell-adjacent neighbours share lines) plus, where a ninth
+// value is needed, an 8/16-B gather from a compact array (16 / 8 particles per line):
+//   pass 1: RecA                      pass 2: RecB + rho_s[j]        pass 3: RecB + bc_s[j]
+struct __attribute__((aligned(64))) RecA {
     double x, y, z;   // position
     double h2;        // h_j^2
     double c1;        // 315 / (64 pi h_j^9)                               nsc:588
     double ms;        // +m (gas), -m (dust), 0 (star): m*[t==0], m*[t==2]  nsc:605-606
     double A;         // m/mu/amu*k*T*[t==0]   pressure weight             nsc:615
     double Nw;        // m/mu/amu*[t==0]       number weight               nsc:607,626
+};
+struct __attribute__((aligned(64))) RecB {
+    double x, y, z, h2;
     double vx, vy, vz;
     double cs;        // sqrt(gamma k T/mu/amu [t==0])   neighbour form    nsc:647
-    double rho;       // written by pass 1                                  nsc:605
+};
+struct __attribute__((aligned(16))) RecBC {   // pass-3 companion
     double Bw;        // m Pi [t==0], written by pass 2                     nsc:651
+    double c1;        // 315 / (64 pi h^9)
+};
+struct __attribute__((aligned(32))) RecSelf { // read only by the owner's thread (coalesced)
     double csi;       // sqrt(gamma k T/(mu amu) [t==0]) own form           nsc:647
     double h;         // smoothing length (crossing time)                   nsc:782
+    double mg;        // m [t==0]
+    double pad;
 };
 
 struct GridParams {
@@ -72,7 +81,8 @@ struct sphx_ctx {
     // ---- working set (any particle order) ----
     int64_t n = 0, npad = 0;
     int k = 0, s = 0;
-    DevBuf rec1, recv;            // Rec[n] (recv unused)
+    DevBuf rec1, recv;            // RecA[n], RecB[n]
+    DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
     const int* map_perm = nullptr;  // device API: sorted -> caller index (nullptr: identity)
     int map_nactive = 0;            // device API: callers' particles below this are computed

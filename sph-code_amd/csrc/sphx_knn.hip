@@ -1,7 +1,7 @@
 // sphx_knn.hip - exact k-nearest-neighbour search on a cell list (replaces nsc:541-552).
 //
 // One 64-wide wavefront per query particle; K <= 64 so the running top-64 candidate set lives
-// in registers, ONE ENTRY PER LANE, kept sorted by a bitonic network on (d^2 bits, id).
+// in registers, ONE ENTRY PER LANE, kept sorted by a bitonic network on (d^2 bits, index).
 //   * particles are cell-sorted (sphx_grid.hip); a row of cells cx0..cx1 at fixed (cy,cz) is
 //     one contiguous range of the sorted arrays, so candidate loads are coalesced SoA reads;
 //   * the rows of the search cube are flattened with a wave prefix sum so every batch of 64
@@ -124,7 +124,10 @@ __device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
     return s;
 }
 
-__global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
+#ifndef KNN_MIN_WAVES
+#define KNN_MIN_WAVES 6      // waves per SIMD the register budget is held to (6 -> <= 80 VGPRs; measured fastest)
+#endif
+__global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     __shared__ int tile[SPHX_MAX_K][KNN_PPB + 1];
     __shared__ u64 stg_key[KNN_BLOCK / 64][128];
     __shared__ u32 stg_id[KNN_BLOCK / 64][128];
@@ -192,36 +195,56 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
             const bool at_bound = (R >= a.rbound);
             u64 tk = (u64)__double_as_longlong(R * R);
             u32 tv = at_bound ? 0u : 0xFFFFFFFFu;
-            const int cx0 = cell_coord(xi - R, g.xmin, g.inv_cell, g.nx - 1);
-            const int cx1 = cell_coord(xi + R, g.xmin, g.inv_cell, g.nx - 1);
+            const double R2 = R * R;
             const int cy0 = cell_coord(yi - R, g.ymin, g.inv_cell, g.ny - 1);
             const int cy1 = cell_coord(yi + R, g.ymin, g.inv_cell, g.ny - 1);
             const int cz0 = cell_coord(zi - R, g.zmin, g.inv_cell, g.nz - 1);
             const int cz1 = cell_coord(zi + R, g.zmin, g.inv_cell, g.nz - 1);
             const int ysp = cy1 - cy0 + 1;
             const int nrows = ysp * (cz1 - cz0 + 1);
+            const float inv_ysp = 1.0f / (float)ysp;
+            const double slack = 1e-9 * g.cell;
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
             bool have_best = false;           // best[] still empty: first flush is a plain sort
 
             for (int rb = 0; rb < nrows; rb += 64) {
+                // ---- one lane per (cy,cz) row of cells: clip the row to the search SPHERE ----
                 const int r = rb + lane;
                 int s_row = 0, cnt = 0;
                 if (r < nrows) {
-                    int cy = cy0 + r % ysp, cz = cz0 + r / ysp;
-                    int row = (cz * g.ny + cy) * g.nx;
-                    s_row = a.cell_start[row + cx0];
-                    cnt = a.cell_start[row + cx1 + 1] - s_row;
+                    const int rz = (nrows <= 65536) ? (int)(((float)r + 0.5f) * inv_ysp) : r / ysp;
+                    const int cy = cy0 + (r - rz * ysp), cz = cz0 + rz;
+                    // distance from the particle to the row's (y,z) cell column.  Boundary cells are
+                    // half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
+                    const double ylo = g.ymin + (double)cy * g.cell, zlo = g.zmin + (double)cz * g.cell;
+                    double dy = 0.0, dz = 0.0;
+                    if (cy > 0) dy = fmax(dy, ylo - yi);
+                    if (cy < g.ny - 1) dy = fmax(dy, yi - (ylo + g.cell));
+                    if (cz > 0) dz = fmax(dz, zlo - zi);
+                    if (cz < g.nz - 1) dz = fmax(dz, zi - (zlo + g.cell));
+                    dy = fmax(dy - slack, 0.0);
+                    dz = fmax(dz - slack, 0.0);
+                    const double rem = R2 - (dy * dy + dz * dz);
+                    if (rem >= 0.0) {         // the row meets the sphere: chord along x
+                        const double half = sqrt(rem) * (1.0 + 1e-12) + slack;
+                        const int rx0 = cell_coord(xi - half, g.xmin, g.inv_cell, g.nx - 1);
+                        const int rx1 = cell_coord(xi + half, g.xmin, g.inv_cell, g.nx - 1);
+                        const int row = (cz * g.ny + cy) * g.nx;
+                        s_row = a.cell_start[row + rx0];
+                        cnt = a.cell_start[row + rx1 + 1] - s_row;
+                    }
                 }
-                int incl = cnt;               // inclusive wave scan
+                int incl = cnt;               // inclusive wave scan: incl[r] = first slot of row r+1
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     int up = __shfl_up(incl, o, 64);
                     if (lane >= o) incl += up;
                 }
-                const int off = incl - cnt;
-                const int T = __shfl(incl, 63, 64);
+                const int sb = s_row - (incl - cnt);      // candidate slot t of row r is particle sb[r] + t
+                const int T = __builtin_amdgcn_readlane(incl, 63);
                 ncand += (u64)T;
 
+                const int off = incl - cnt;
                 for (int t0 = 0; t0 < T; t0 += 64) {
                     const int t = t0 + lane;
                     const bool valid = t < T;
@@ -233,13 +256,13 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
                         int v = __shfl(off, pr, 64);
                         if (v <= tt) rr = pr;
                     }
-                    const int p = __shfl(s_row, rr, 64) + (tt - __shfl(off, rr, 64));
+                    const int p = __shfl(sb, rr, 64) + tt;
                     const double d2 = dist2_nofma(a.x[p] - xi, a.y[p] - yi, a.z[p] - zi);
                     const u64 key = (u64)__double_as_longlong(d2);
                     // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass.
-                    // The id (tie-break) is only fetched for lanes that can still qualify.
-                    u32 pid = 0xFFFFFFFFu;
-                    if (valid && key <= tk) pid = (u32)a.id[p];
+                    // ties in d2 are broken by the candidate's position in the cell-sorted order,
+                    // which sphx_grid.hip makes deterministic (cells sorted by previous index)
+                    const u32 pid = (u32)p;
                     const bool keep = valid && kv_less(key, pid, tk, tv);
                     const u64 mask = __ballot(keep);
                     const int c = __popcll(mask);
@@ -289,8 +312,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
             }
             const u64 kth = __shfl(bk, K - 1, 64);
             const bool full = (kth != KNN_INF);
-            const bool covers = (cx0 == 0 && cy0 == 0 && cz0 == 0 && cx1 == g.nx - 1 &&
-                                 cy1 == g.ny - 1 && cz1 == g.nz - 1);
+            // the sphere contains the whole grid box: every particle has been a candidate
+            const double gx = g.cell * g.nx, gy = g.cell * g.ny, gz = g.cell * g.nz;
+            const bool covers = !(R2 < gx * gx + gy * gy + gz * gz);
             done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
             if (!done) {
                 R *= 1.6;
@@ -307,8 +331,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(KnnArgs a) {
         const double hval = found > 0 ? dlast : 0.0;
         const int oid = a.id[i];
         if (lane < K) {
-            if (a.nbr) tile[lane][li] = valid ? a.inv[bv] : -1;
-            if (a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)bv : (long long)a.n;
+            if (a.nbr) tile[lane][li] = valid ? (int)bv : -1;
+            if (a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
             if (a.dist) a.dist[(long long)oid * K + lane] = d;
         }
         if (lane == 0) {
@@ -355,7 +379,6 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.nontriv = (long long*)out.nontriv;
     a.h_by_id = out.h_by_id;
     a.counters = ctx->scal.as<u64>();
-    if (a.nbr && !a.inv) return sphx_set_err(ctx, SPHX_E_ARG, "internal list needs the inverse permutation");
     int blocks = (int)(sphx_pad64(n) / KNN_PPB);
     hipLaunchKernelGGL(knn_kernel, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());

@@ -1,7 +1,7 @@
 // sphx_sums.hip - kernel-weighted SPH summations of nsc.hydro_update (nsc:556-671).
 //
 // Three dependent passes over a K-major int32 neighbour list nbr[k][npad] (coalesced for one
-// thread per particle), gathering one 128-B record per neighbour (struct Rec):
+// thread per particle), gathering dense 64-B records per neighbour (RecA / RecB):
 //   pass 1  rho, rho_dust, n, grad P            needs h_j        nsc:588-619
 //   pass 2  Pi_i = sum_k pi_ik, crossing time   needs rho_j      nsc:639-649, nsc:776-786
 //   pass 3  viscous accel + heat                needs Pi_j       nsc:651-654
@@ -20,7 +20,7 @@ struct PrepArgs {
     const double *vx, *vy, *vz; int vs;
     const double *m, *h, *T, *mu, *gam, *ptype;
     double kB, amu;
-    Rec* rec;
+    RecA* ra; RecB* rb; RecBC* bc; RecSelf* self;
     const int* perm;                       // sorted -> caller index of the inputs (nullptr: identity)
 };
 
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     const int i = a.perm ? a.perm[t] : t;
     const double m = a.m[i], h = a.h[i], T = a.T[i], mu = a.mu[i], gam = a.gam[i], pt = a.ptype[i];
     const double g = (pt == 0.0) ? 1.0 : 0.0;
-    Rec r;
+    RecA r; RecB v;
     r.x = a.x[(size_t)i * a.ps]; r.y = a.y[(size_t)i * a.ps]; r.z = a.z[(size_t)i * a.ps];
     const double h2 = h * h, h4 = h2 * h2, h8 = h4 * h4;
     r.h2 = h2;
@@ -39,20 +39,28 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     const double nw = m / mu / a.amu;
     r.A = nw * a.kB * T * g;                                  // nsc:615
     r.Nw = nw * g;                                            // nsc:607, nsc:626
-    r.vx = a.vx[(size_t)i * a.vs]; r.vy = a.vy[(size_t)i * a.vs]; r.vz = a.vz[(size_t)i * a.vs];
-    r.cs = sqrt(gam * a.kB * T / mu / a.amu * g);             // nsc:647 neighbour form
-    r.rho = 0.0;
-    r.Bw = 0.0;
-    r.csi = sqrt(gam * a.kB * T / (mu * a.amu) * g);          // nsc:647 own form
-    r.h = h;
-    a.rec[t] = r;
+    v.x = r.x; v.y = r.y; v.z = r.z; v.h2 = h2;
+    v.vx = a.vx[(size_t)i * a.vs]; v.vy = a.vy[(size_t)i * a.vs]; v.vz = a.vz[(size_t)i * a.vs];
+    v.cs = sqrt(gam * a.kB * T / mu / a.amu * g);             // nsc:647 neighbour form
+    RecBC bc; bc.Bw = 0.0; bc.c1 = r.c1;
+    RecSelf sf;
+    sf.csi = sqrt(gam * a.kB * T / (mu * a.amu) * g);         // nsc:647 own form
+    sf.h = h; sf.mg = m * g; sf.pad = 0.0;
+    a.ra[t] = r;
+    a.rb[t] = v;
+    a.bc[t] = bc;
+    a.self[t] = sf;
 }
 
 int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
               const double* pos_aos, const double* vx, const double* vy, const double* vz,
               const double* vel_aos, const double* m, const double* h, const double* T,
               const double* mu, const double* gam, const double* ptype) {
-    SPHX_TRY(sphx_ensure(ctx, ctx->rec1, (size_t)n * sizeof(Rec)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->rec1, (size_t)n * sizeof(RecA)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->recv, (size_t)n * sizeof(RecB)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->rho_s, (size_t)n * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->bc_s, (size_t)n * sizeof(RecBC)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->self_s, (size_t)n * sizeof(RecSelf)));
     PrepArgs a;
     a.n = (int)n;
     if (pos_aos) { a.x = pos_aos; a.y = pos_aos + 1; a.z = pos_aos + 2; a.ps = 3; }
@@ -61,7 +69,10 @@ int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     else { a.vx = vx; a.vy = vy; a.vz = vz; a.vs = 1; }
     a.m = m; a.h = h; a.T = T; a.mu = mu; a.gam = gam; a.ptype = ptype;
     a.kB = ctx->cst.k_B; a.amu = ctx->cst.amu;
-    a.rec = ctx->rec1.as<Rec>();
+    a.ra = ctx->rec1.as<RecA>();
+    a.rb = ctx->recv.as<RecB>();
+    a.bc = ctx->bc_s.as<RecBC>();
+    a.self = ctx->self_s.as<RecSelf>();
     a.perm = ctx->map_perm;
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
@@ -105,9 +116,15 @@ __device__ __forceinline__ Q4 load4(const double* p) {
     return Q4{lo.x, lo.y, hi.x, hi.y};
 }
 
+// The neighbour loops run in chunks of NBATCH: all NBATCH indices are fetched first, then all
+// NBATCH records, so several independent gathers are in flight per lane before the first use
+// (the passes are bound by gather latency, not arithmetic); the sums still accumulate in list order.
+#define NBATCH 4
+
 // ---- pass 1 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                           Rec* rec, OutMap om, double* rho,
+                                                           const RecA* __restrict__ rec, double* rho_s,
+                                                           OutMap om, double* rho,
                                                            double* rhod, double* nden, double* G,
                                                            double* ha) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -121,11 +138,20 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
     if (j0 >= 0 && j0 != i) { xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
     const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
     double s_rho = 0.0, s_rd = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    for (int kk = 0; kk < k; ++kk) {
-        int j = nbr[(size_t)kk * npad + i];
-        if (j < 0) continue;
-        const double* q = reinterpret_cast<const double*>(&rec[j]);
-        const Q4 q0 = load4(q), q1 = load4(q + 4);
+    for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
+      int jb[NBATCH];
+      Q4 q0b[NBATCH], q1b[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+          const double* q = reinterpret_cast<const double*>(&rec[jb[u] < 0 ? i : jb[u]]);
+          q0b[u] = load4(q); q1b[u] = load4(q + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        if (jb[u] < 0) continue;
+        const Q4 q0 = q0b[u], q1 = q1b[u];
         const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
         const double r2 = r * r;                              // nsc:588 squares the rounded distance
@@ -142,9 +168,10 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         gx += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;        // nsc:615
         gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
         gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
+      }
     }
     rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
-    rec[i].rho = s_rho;                                       // read by pass 2 (next kernel)
+    rho_s[i] = s_rho;                                         // sorted order: gathered by pass 2
     G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
     ha[3 * (size_t)o + 0] = -gx / s_rho;                      // nsc:619
     ha[3 * (size_t)o + 1] = -gy / s_rho;
@@ -158,8 +185,8 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
     hipLaunchKernelGGL(pass_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
-                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
+                       ctx->rho_s.as<double>(), OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
                        ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
@@ -182,25 +209,40 @@ __device__ __forceinline__ u64 block_min_u64(u64 v) {
 }
 
 __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                      Rec* rec, OutMap om, double* Pi, double* BwOut,
+                                                      const RecB* __restrict__ recb,
+                                                      const double* __restrict__ rho_s,
+                                                      const RecSelf* __restrict__ selfr, RecBC* bc,
+                                                      OutMap om, double* Pi, double* BwOut,
                                                       u64* ct_bits) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
     const int o = (i < n) ? out_index(om, i) : 0x7FFFFFFF;
     if (i < n && o < om.n_active) {
-        const Rec* self = &rec[i];
         int j0 = nbr[i];
         if (j0 < 0) j0 = i;
-        const double* rq = reinterpret_cast<const double*>(&rec[j0]);
-        const Q4 r0 = load4(rq), rv = load4(rq + 8);          // x y z h2 | vx vy vz cs
-        const double rho_i = self->rho, cs_i = self->csi, ms_i = self->ms, h_i = self->h;
+        const double* rq = reinterpret_cast<const double*>(&recb[j0]);
+        const Q4 r0 = load4(rq), rv = load4(rq + 4);                         // x y z h2 | vx vy vz cs
+        const RecSelf sf = selfr[i];
+        const double rho_i = rho_s[i], cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
         double s_pi = 0.0, maxrel = 0.0;
-        for (int kk = 0; kk < k; ++kk) {
-            int j = nbr[(size_t)kk * npad + i];
-            if (j < 0) continue;
-            const double* q = reinterpret_cast<const double*>(&rec[j]);
-            const Q4 q0 = load4(q), qv = load4(q + 8);
-            const double rho_j = q[12];
+        for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
+          int jb[NBATCH];
+          Q4 q0b[NBATCH], qvb[NBATCH];
+          double rhob[NBATCH];
+#pragma unroll
+          for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+#pragma unroll
+          for (int u = 0; u < NBATCH; ++u) {
+              const int jj = jb[u] < 0 ? i : jb[u];
+              const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+              q0b[u] = load4(qb); qvb[u] = load4(qb + 4);
+              rhob[u] = rho_s[jj];
+          }
+#pragma unroll
+          for (int u = 0; u < NBATCH; ++u) {
+            if (jb[u] < 0) continue;
+            const Q4 q0 = q0b[u], qv = qvb[u];
+            const double rho_j = rhob[u];
             const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
             const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
             const double r2 = dx * dx + dy * dy + dz * dz;
@@ -211,10 +253,11 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
             const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
             s_pi += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;             // nsc:649
             maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);       // nsc:780
+          }
         }
         Pi[o] = s_pi;
         const double bw = fmax(ms_i, 0.0) * s_pi;                           // m Pi [t==0]  nsc:651
-        rec[i].Bw = bw;
+        bc[i].Bw = bw;
         if (BwOut) BwOut[o] = bw;
         if (ms_i > 0.0) {                                                   // gas only     nsc:782
             double ct = h_i / sqrt(maxrel);
@@ -234,7 +277,8 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
+                       ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(),
                        OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->Pi.as<double>(), ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct);
     HIPCHK(hipGetLastError());
@@ -243,26 +287,40 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
 
 // ---- pass 3 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
-                                                        const Rec* __restrict__ rec, OutMap om,
+                                                        const RecB* __restrict__ recb,
+                                                        const RecBC* __restrict__ bc, OutMap om,
                                                         const double* __restrict__ m, double* va,
                                                         double* vh) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int o = out_index(om, i);
     if (o >= om.n_active) return;
-    const Rec* self = &rec[i];
     int j0 = nbr[i];
     if (j0 < 0) j0 = i;
-    const double* rq = reinterpret_cast<const double*>(&rec[j0]);
-    const Q4 r0 = load4(rq), rv = load4(rq + 8);
-    const double hi2 = self->h2, ci = -6.0 * self->c1, Bi = self->Bw;
+    const double* rq = reinterpret_cast<const double*>(&recb[j0]);
+    const Q4 r0 = load4(rq), rv = load4(rq + 4);
+    const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
+    const double hi2 = recb[i].h2, ci = -6.0 * bci.y, Bi = bci.x;
     double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
-    for (int kk = 0; kk < k; ++kk) {
-        int j = nbr[(size_t)kk * npad + i];
-        if (j < 0) continue;
-        const double* q = reinterpret_cast<const double*>(&rec[j]);
-        const Q4 q0 = load4(q), qv = load4(q + 8);
-        const double c1 = q[4], Bj = q[13];
+    for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
+      int jb[NBATCH];
+      Q4 q0b[NBATCH], qvb[NBATCH];
+      double2 bcb[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+          const int jj = jb[u] < 0 ? i : jb[u];
+          const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+          q0b[u] = load4(qb); qvb[u] = load4(qb + 4);
+          bcb[u] = *reinterpret_cast<const double2*>(&bc[jj]);
+      }
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        if (jb[u] < 0) continue;
+        const Q4 q0 = q0b[u], qv = qvb[u];
+        const double2 bcj = bcb[u];
+        const double c1 = bcj.y, Bj = bcj.x;
         const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const double r2 = r * r;
@@ -274,6 +332,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
         ax += bx; ay += by; az += bz;
         heat += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
+      }
     }
     va[3 * (size_t)o + 0] = -ax; va[3 * (size_t)o + 1] = -ay; va[3 * (size_t)o + 2] = -az;
     vh[o] = heat * m[o] / 2.0;                                              // nsc:654  (m in output order)
@@ -283,8 +342,8 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->va, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(),
-                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
+                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
+                       ctx->bc_s.as<RecBC>(), OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
                        ctx->va.as<double>(), ctx->vh.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -294,7 +353,7 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
 #define SPEC_CHUNK 8
 __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int k, int S,
                                                            const int* __restrict__ nbr,
-                                                           const Rec* __restrict__ rec,
+                                                           const RecA* __restrict__ rec,
                                                            const double* __restrict__ fun, double* F) {
     int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -305,6 +364,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
     double acc[SPEC_CHUNK];
 #pragma unroll
     for (int q = 0; q < SPEC_CHUNK; ++q) acc[q] = 0.0;
+#pragma unroll 4
     for (int kk = 0; kk < k; ++kk) {
         int j = nbr[(size_t)kk * npad + i];
         if (j < 0) continue;
@@ -330,7 +390,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F) {
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)((s + SPEC_CHUNK - 1) / SPEC_CHUNK));
     hipLaunchKernelGGL(pass_species_kernel, grid, dim3(256), 0, ctx->stream, (int)n,
-                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<Rec>(), fun, F);
+                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun, F);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
