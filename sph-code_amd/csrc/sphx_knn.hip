@@ -116,6 +116,14 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
     return (int)t;
 }
 
+// broadcast lane `src` (wave-uniform) of a double / int to the whole wave through SGPRs
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, src);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)b >> 32), src);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
 #pragma clang fp contract(off)
     double s = dx * dx;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     __shared__ u32 stg_id[KNN_BLOCK / 64][128];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int base = xcd_block(blockIdx.x, gridDim.x) * KNN_PPB;
     const GridParams g = a.g;
     const int K = a.k;
@@ -141,25 +149,35 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     u32* sid = stg_id[wave];
     u64 ncand = 0, nretry = 0;
 
+    // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
+    // particle l) and broadcast through SGPRs as each comes up
+    double qx = 0.0, qy = 0.0, qz = 0.0, qr = 0.0;
+    int qid = 0x7FFFFFFF;
+    {
+        const int ip = base + wave * (KNN_PPB / 4) + (lane & 15);
+        if (lane < KNN_PPB / 4 && ip < a.n) {
+            qx = a.x[ip]; qy = a.y[ip]; qz = a.z[ip];
+            qid = a.id[ip];
+            qr = a.rsearch ? a.rsearch[a.hint_by_id ? qid : ip] * a.rscale : 0.0;
+        }
+    }
+
     for (int t16 = 0; t16 < KNN_PPB / 4; ++t16) {
         const int li = wave * (KNN_PPB / 4) + t16;
         const int i = base + li;
-        if (i >= a.n) {                       // wave-uniform
+        const int oid = __builtin_amdgcn_readlane(qid, t16);
+        // wave-uniform: past the end, or a ghost (a candidate, never a query)
+        if (i >= a.n || oid >= a.n_active) {
             if (lane < K) tile[lane][li] = -1;
             continue;
         }
-        if (a.id[i] >= a.n_active) {          // wave-uniform: a ghost is a candidate, not a query
-            if (lane < K) tile[lane][li] = -1;
-            continue;
-        }
-        const double xi = a.x[i], yi = a.y[i], zi = a.z[i];
-        const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
-        const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
-        const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
-
-        double R = a.rsearch ? a.rsearch[a.hint_by_id ? a.id[i] : i] * a.rscale : 0.0;
+        const double xi = bcast_f64(qx, t16), yi = bcast_f64(qy, t16), zi = bcast_f64(qz, t16);
+        double R = bcast_f64(qr, t16);
         if (!(R > 0.0)) {
             // density estimate from the 3x3x3 block of cells around the particle
+            const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
+            const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
+            const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
             int cnt = 0, nc = 0;
             if (lane < 9) {
                 int cy = cyi - 1 + lane % 3, cz = czi - 1 + lane / 3;
@@ -329,7 +347,6 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         const double d = valid ? sqrt(__longlong_as_double((long long)bk)) : 0.0;
         const double dlast = __shfl(d, found > 0 ? found - 1 : 0, 64);
         const double hval = found > 0 ? dlast : 0.0;
-        const int oid = a.id[i];
         if (lane < K) {
             if (a.nbr) tile[lane][li] = valid ? (int)bv : -1;
             if (a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
