@@ -15,6 +15,7 @@
 // Distances are accumulated as ((dx*dx + dy*dy) + dz*dz) without FMA contraction, the same
 // arithmetic SciPy's cKDTree uses, so orderings agree with the oracle bit for bit.
 #include "sphx_internal.h"
+#include <stdlib.h>
 
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
@@ -110,6 +111,80 @@ __device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int la
     merge_stage<32>(bk, bv, lane);
 }
 
+// ---- 32-bit network: the common case -------------------------------------------------------
+// Staged survivors sit in LDS; their order is found on a UNIQUE 32-bit key
+//     (monotone 26-bit quantisation of d2 / R^2) << 6 | staging slot
+// so one exchange + v_min/v_max/v_cndmask does a compare-exchange (vs 3 exchanges + 3 compares
+// + 3 selects on (u64,u32)).  The full (d2 bits, index) pairs are then fetched from LDS by
+// slot.  Two survivors in the same quantisation bin (about 1 particle in 40 000) are put into
+// their exact order by a few odd-even steps with the full compare.
+template <int J> __device__ __forceinline__ void cmpx32(u32& k, bool keep_min) {
+    const u32 p = xchg32<J>(k);
+    const u32 mn = k < p ? k : p, mx = k < p ? p : k;
+    k = keep_min ? mn : mx;
+}
+template <int SIZE, int J> __device__ __forceinline__ void sort32_stage(u32& k, int lane) {
+    const bool up = (lane & SIZE) == 0;
+    const bool lower = (lane & J) == 0;
+    cmpx32<J>(k, lower == up);
+    if constexpr (J > 1) sort32_stage<SIZE, J / 2>(k, lane);
+}
+template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lane) {
+    if constexpr (SIZE > 2) sort32_sizes<SIZE / 2>(k, lane);
+    sort32_stage<SIZE, SIZE / 2>(k, lane);
+}
+
+// Sort the `cnt` staged entries at ring position `head` ascending by (key, index) into (ck, cv);
+// lanes >= cnt get the (INF, ~0) padding.  r2 = trial radius^2 bounds every staged key.
+template <int ABL>
+__device__ __forceinline__ void sort_staged(const u64* skey, const u32* sid, int head, int cnt, double r2,
+                                            int lane, u64& ck, u32& cv) {
+    ck = KNN_INF;
+    cv = 0xFFFFFFFFu;
+    if (lane < cnt) {
+        ck = skey[(head + lane) & 127];
+        cv = sid[(head + lane) & 127];
+    }
+    if (ABL == 1) return;              // timing experiment: no ordering network
+    if (!(r2 > 0.0) || !(r2 < 1e300)) {       // degenerate radius: full-key network
+        sort64(ck, cv, lane, false);
+        return;
+    }
+    const double qd = fmin(__longlong_as_double((long long)ck) * (67108862.0 / r2), 67108862.0);
+    u32 k32 = (lane < cnt) ? (((u32)qd << 6) | (u32)lane) : 0xFFFFFFFFu;
+    sort32_sizes<64>(k32, lane);
+    const bool v = (k32 != 0xFFFFFFFFu);
+    const int slot = (head + (int)(k32 & 63u)) & 127;
+    ck = v ? skey[slot] : KNN_INF;
+    cv = v ? sid[slot] : 0xFFFFFFFFu;
+    const u32 nextq = (u32)__shfl_down((int)(k32 >> 6), 1, 64);
+    if (__ballot(v && lane < 63 && nextq == (k32 >> 6))) {
+        // same-bin neighbours: odd-even transposition on the exact keys until ordered
+        for (int it = 0; it < 64; ++it) {
+            u64 k0 = ck; u32 v0 = cv;
+            cmpx<1>(ck, cv, (lane & 1) == 0);                          // pairs (0,1)(2,3)...
+            const int partner = (lane & 1) ? lane + 1 : lane - 1;     // pairs (1,2)(3,4)...
+            const int pc = partner < 0 ? 0 : (partner > 63 ? 63 : partner);
+            const u64 pk = __shfl(ck, pc, 64);
+            const u32 pv = __shfl(cv, pc, 64);
+            if (partner >= 0 && partner <= 63) {
+                const bool p_lt = kv_less(pk, pv, ck, cv);
+                const bool keep_min = (lane & 1) != 0;                  // the odd lane is the lower of its pair
+                if (p_lt == keep_min) { ck = pk; cv = pv; }
+            }
+            if (!__ballot(k0 != ck || v0 != cv)) break;
+        }
+    }
+}
+
+// merge an ascending `cand` into the ascending `best` (both 64 wide): 64 smallest, ascending
+__device__ __forceinline__ void merge_sorted(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
+    const u64 rk = __shfl(ck, 63 - lane, 64);
+    const u32 rv = __shfl(cv, 63 - lane, 64);
+    if (kv_less(rk, rv, bk, bv)) { bk = rk; bv = rv; }   // bitonic: min of asc and desc
+    merge_stage<32>(bk, bv, lane);
+}
+
 __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell, int nmax1) {
     double t = (v - vmin) * inv_cell;
     t = fmin(fmax(t, 0.0), (double)nmax1);
@@ -135,6 +210,9 @@ __device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
 #ifndef KNN_MIN_WAVES
 #define KNN_MIN_WAVES 6      // waves per SIMD the register budget is held to (6 -> <= 80 VGPRs; measured fastest)
 #endif
+// ABL != 0: timing experiments with a section removed (outputs are then meaningless and are
+// never written: the wrapper passes null output pointers); ABL == 0 is the product kernel.
+template <int ABL>
 __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     __shared__ int tile[SPHX_MAX_K][KNN_PPB + 1];
     __shared__ u64 stg_key[KNN_BLOCK / 64][128];
@@ -225,7 +303,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
             bool have_best = false;           // best[] still empty: first flush is a plain sort
 
-            for (int rb = 0; rb < nrows; rb += 64) {
+            for (int rb = 0; rb < (ABL == 3 ? 0 : nrows); rb += 64) {
                 // ---- one lane per (cy,cz) row of cells: clip the row to the search SPHERE ----
                 const int r = rb + lane;
                 int s_row = 0, cnt = 0;
@@ -263,7 +341,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 ncand += (u64)T;
 
                 const int off = incl - cnt;
-                for (int t0 = 0; t0 < T; t0 += 64) {
+                for (int t0 = 0; t0 < (ABL == 2 ? 0 : T); t0 += 64) {
                     const int t = t0 + lane;
                     const bool valid = t < T;
                     const int tt = valid ? t : 0;
@@ -284,7 +362,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     const bool keep = valid && kv_less(key, pid, tk, tv);
                     const u64 mask = __ballot(keep);
                     const int c = __popcll(mask);
-                    if (c) {
+                    if (c && ABL != 4) {
                         if (keep) {
                             int pos = (head + nst + __popcll(mask & ((1ull << lane) - 1ull))) & 127;
                             skey[pos] = key;
@@ -293,15 +371,14 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                         nst += c;
                         if (nst >= 64) {
                             wave_sync();
-                            u64 ck = skey[(head + lane) & 127];
-                            u32 cv = sid[(head + lane) & 127];
+                            u64 ck; u32 cv;
+                            sort_staged<ABL>(skey, sid, head, 64, R2, lane, ck, cv);
                             wave_sync();
                             head = (head + 64) & 127;
                             nst -= 64;
                             if (have_best) {
-                                merge64(bk, bv, ck, cv, lane);
+                                merge_sorted(bk, bv, ck, cv, lane);
                             } else {
-                                sort64(ck, cv, lane, false);
                                 bk = ck; bv = cv;
                                 have_best = true;
                             }
@@ -314,17 +391,12 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             }
             if (nst > 0) {
                 wave_sync();
-                u64 ck = KNN_INF;
-                u32 cv = 0xFFFFFFFFu;
-                if (lane < nst) {
-                    ck = skey[(head + lane) & 127];
-                    cv = sid[(head + lane) & 127];
-                }
+                u64 ck; u32 cv;
+                sort_staged<ABL>(skey, sid, head, nst, R2, lane, ck, cv);
                 wave_sync();
                 if (have_best) {
-                    merge64(bk, bv, ck, cv, lane);
+                    merge_sorted(bk, bv, ck, cv, lane);
                 } else {
-                    sort64(ck, cv, lane, false);
                     bk = ck; bv = cv;
                 }
             }
@@ -334,6 +406,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             const double gx = g.cell * g.nx, gy = g.cell * g.ny, gz = g.cell * g.nz;
             const bool covers = !(R2 < gx * gx + gy * gy + gz * gz);
             done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
+            if (ABL != 0) done = true;    // timing experiments never retry
             if (!done) {
                 R *= 1.6;
                 if (R > a.rbound) R = a.rbound;
@@ -397,7 +470,27 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.h_by_id = out.h_by_id;
     a.counters = ctx->scal.as<u64>();
     int blocks = (int)(sphx_pad64(n) / KNN_PPB);
-    hipLaunchKernelGGL(knn_kernel, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
+    if (const char* e = getenv("SPHX_KNN_ABL")) {       // timing experiment, results discarded
+        KnnArgs b = a;
+        b.nbr = nullptr; b.h_sorted = nullptr; b.idx64 = nullptr; b.dist = nullptr; b.nontriv = nullptr;
+        b.h_by_id = nullptr; b.counters = nullptr;
+        const int mode = atoi(e);
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+        if (mode == 1) hipLaunchKernelGGL(knn_kernel<1>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        else if (mode == 2) hipLaunchKernelGGL(knn_kernel<2>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        else if (mode == 3) hipLaunchKernelGGL(knn_kernel<3>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        else if (mode == 4) hipLaunchKernelGGL(knn_kernel<4>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(knn_kernel<0>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        fprintf(stderr, "[sphx] knn ablation %d: %.4f ms\n", mode, ms);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    hipLaunchKernelGGL(knn_kernel<0>, dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
