@@ -14,10 +14,13 @@ design, following SURVEY.md 8(e):
   * exchange = grouped isend/irecv between the (at most world-1) peers that share a halo, no
     collective on the data path; the only collectives are two scalars per step (halo widths:
     all_gather of one double; dt: all_reduce(min) of the crossing time, nsc:786);
-  * after the leapfrog update particles that left their region migrate to the new owner.
+  * the send lists (the "plan") are reused from step to step with a skin, molecular-dynamics
+    style: they are rebuilt - and particles that left their region migrate to the new owner -
+    only when displacements since the last plan exceed half the skin.
 
-The halo width is verified after every search (all owned h_i <= width, otherwise the step's
-exchange is redone with a wider halo), so the decomposed result equals the single-GPU result.
+Halo coverage is verified after every search (h_i + 2 x displacement <= width for every owned
+particle, otherwise all ranks replan with a wider halo and redo the search), so the decomposed
+result equals the single-GPU result.
 
 Compute is injected through a small backend interface; the product backend `LibBackend` calls
 libsphx.so's sphx_dev_* entry points on the rank's GPU (no CPU fallback).
@@ -216,7 +219,7 @@ class DistributedSim:
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
     def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
-                 halo_scale=1.15):
+                 halo_scale=1.15, skin_frac=0.15):
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
@@ -233,6 +236,8 @@ class DistributedSim:
         self.lo = torch.as_tensor(lo, dtype=torch.float64).to(self.device)
         self.hi = torch.as_tensor(hi, dtype=torch.float64).to(self.device)
         self.halo_scale = halo_scale
+        self.skin_frac = skin_frac          # plan is reused while displacements stay below skin/2
+        self.plan_w, self.send_idx, self.recv_counts, self.pos_plan = 0.0, None, None, None
         self.first = True
         self.dt_last = 0.0
         self.last = {}
@@ -290,24 +295,55 @@ class DistributedSim:
         return torch.zeros((0, w), dtype=torch.float64, device=owned_rows.device)
 
     # ------------------------------------------------------------------------------------------
+    def _replan(self, my_w):
+        """Migrate strays to their region's owner, then rebuild the send lists for halo width my_w
+        (+ skin).  The plan stays valid while nobody has moved more than skin/2 since (see step)."""
+        self._migrate()
+        s = self.s
+        self.plan_w = my_w
+        widths = self._allgather_scalar(my_w)
+        self.send_idx, self.recv_counts = self._plan(widths)
+        self.pos_plan = s["pos"].clone()
+        self.stats["replans"] = self.stats.get("replans", 0) + 1
+
     def step(self, fixed_dt=0.0):
-        s, be, no = self.s, self.backend, self.n_owned
+        """One decomposed pass of the hot path.
+
+        Halo validity with a reused plan.  Let W be this rank's halo width when the plan was made
+        (all foreign particles within W of the region became ghosts; owned particles were inside
+        the region) and D the largest displacement of ANY particle since.  An owned particle is now
+        at most D outside the region and a foreign non-ghost is still more than W - D from it, so
+        every neighbour within h_i of an owned particle is owned or a ghost as long as
+        h_i + 2D <= W.  That is checked after every search; a failing rank widens and replans.
+        A new plan is also made as soon as 2D exceeds the skin, so the check rarely fails."""
+        s, be = self.s, self.backend
         be.clamp(s["pos"], s["vel"])                                        # drv:233-238
-        if self.first or float(s["h"].max()) <= 0.0:
-            # bootstrap: a search without ghosts over-estimates every h (fewer candidates), so its
-            # maximum is a rigorous halo width for the first exchange
+        no = self.n_owned
+        bootstrap = self.first or no == 0 or float(s["h"].max()) <= 0.0
+        if bootstrap:
+            # a search without ghosts over-estimates every h (fewer candidates), so its maximum is
+            # a rigorous halo width for the first exchange
             hloc = be.search(s["pos"], no, None, 0.0)
-            my_w = float(hloc[:no].max()) if no else 0.0
-            hint_owned = None
-            mean_h = float(hloc[:no].mean()) if no else 0.0
+            hmax0 = float(hloc[:no].max()) if no else 0.0
+            self._replan(hmax0 * (1.0 + self.skin_frac))
+            D = 0.0
         else:
-            my_w = self.halo_scale * float(s["h"].max())
-            hint_owned = s["h"]
-            mean_h = float(s["h"].mean())
+            d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772 if no else 0.0
+            D = self._allreduce_max(d_loc)                    # bound on the displacement norm
+            hmax0 = float(s["h"].max())
+            if 2.0 * D > self.skin_frac * hmax0 or self.halo_scale * hmax0 + 2.0 * D > self.plan_w:
+                need = 1.0
+            else:
+                need = 0.0
+            if self._allreduce_max(need) > 0.5:
+                self._replan((self.halo_scale + self.skin_frac) * hmax0)
+                D = 0.0
         while True:
-            widths = self._allgather_scalar(my_w)
-            send_idx, recv_counts = self._plan(widths)
+            s, no = self.s, self.n_owned                      # (a replan may have migrated particles)
+            send_idx, recv_counts = self.send_idx, self.recv_counts
             ng = sum(recv_counts)
+            hint_owned = None if float(s["h"].max() if no else 0.0) <= 0.0 else s["h"]
+            mean_h = float(s["h"].mean()) if hint_owned is not None else 0.0
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
             owned_rows = torch.cat([s["pos"], s["vel"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
                                     s["gam"][:, None], s["ptype"][:, None], s["h"][:, None]], dim=1)
@@ -320,11 +356,12 @@ class DistributedSim:
             hint = None if hint_owned is None else cat1(hint_owned, 11)
             h = be.search(pos, no, hint, mean_h)
             hmax = float(h[:no].max()) if no else 0.0
-            ok_local = 1.0 if hmax <= my_w else 0.0
-            if self._allreduce_min(ok_local) > 0.5:
+            bad = 0.0 if hmax + 2.0 * D <= self.plan_w else 1.0
+            if self._allreduce_max(bad) < 0.5:
                 break
-            if hmax > my_w:                       # a kNN radius outgrew the halo: widen and redo
-                my_w = 1.5 * hmax
+            # a kNN radius outgrew the halo somewhere: everybody replans (wider where needed)
+            self._replan(max(self.plan_w, 1.5 * hmax * (1.0 + self.skin_frac)) if bad else self.plan_w)
+            D = 0.0
             self.stats["redo"] += 1
         # ---- halo phase 2: ghosts' h_j ----------------------------------------------------------
         gh = self._halo(send_idx, recv_counts, h[:no, None])
@@ -357,7 +394,6 @@ class DistributedSim:
         self.first = False
         self.stats["steps"] += 1
         self.stats["ghosts"] += ng
-        self._migrate()
 
     # ------------------------------------------------------------------------------------------
     def _migrate(self):
@@ -370,6 +406,9 @@ class DistributedSim:
         send_idx = [None if p == self.rank else torch.nonzero(owner == p).flatten() for p in range(self.world)]
         counts = [0 if ix is None else int(ix.numel()) for ix in send_idx]
         recv_counts = self.ex.counts(counts)
+        if not self.last:
+            z = torch.zeros(s["pos"].shape[0], dtype=torch.float64, device=s["pos"].device)
+            self.last = dict(rho=z, nden=z.clone(), visc_heat=z.clone())
         extra = [self.last[k_][:, None] for k_ in ("rho", "nden", "visc_heat")]
         rows = torch.cat([s["pos"], s["vel"], s["acc"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
                           s["gam"][:, None], s["ptype"][:, None], s["E"][:, None], s["h"][:, None],

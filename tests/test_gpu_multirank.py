@@ -58,7 +58,8 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir):
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
-    res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent])
+    res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
+                             sim.stats.get("replans", 0)])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
