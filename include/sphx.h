@@ -67,6 +67,8 @@ typedef struct sphx_stats {
     int64_t candidates;    /* candidate distance evaluations in the search      */
     int64_t retries;       /* searches repeated with a larger radius            */
     int64_t cells;         /* cells of the last grid                            */
+    int64_t refresh_steps; /* steps whose kNN came from the Verlet lists         */
+    int64_t rebuild_steps; /* steps with cell sort + full search                 */
     double  cell_size;     /* edge of the last grid's cells                     */
 } sphx_stats;
 
@@ -81,6 +83,13 @@ int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
  * rscale * h_previous (default 1.2) and bins particles into cells of edge
  * cell_factor * mean(h) (default 0.6).  Values <= 0 keep the current setting. */
 int         sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor);
+/* Incremental search (off by default).  With verlet != 0 a full search also keeps each
+ * particle's 64 nearest candidates; following steps take the exact kNN from those lists as long
+ * as it can be PROVEN exact from the displacements since (sphx_refresh.hip), else the step
+ * rebuilds.  It pays when the fastest particle moves much less than 0.08 h per step; in the
+ * BASELINE workloads (dt >= dt_0/5, sph/code_running.py:226) it does not, hence the default.
+ * rscale_build (default 1.3, <= 0 keeps) is the search radius factor on rebuilding steps.      */
+int         sphx_set_incremental(sphx_ctx* ctx, int verlet, double rscale_build);
 
 /* ---- nsc.neighbors(points, dist, N_NEIGH)                          nsc:541-552 ----- *
  * Exact k nearest neighbours (Euclidean) within `dist`; `eps` is accepted for API

@@ -19,7 +19,8 @@ class SphxConstants(C.Structure):
 class SphxStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi",
                                           "ms_visc", "ms_integrate", "ms_total")] + \
-               [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells")] + \
+               [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
+                                         "rebuild_steps")] + \
                [("cell_size", C.c_double)]
 
     def as_dict(self):
@@ -38,6 +39,7 @@ SIGNATURES = {
     "sphx_set_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
     "sphx_get_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
     "sphx_set_tuning": (C.c_int, [_P, C.c_double, C.c_double]),
+    "sphx_set_incremental": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_neighbors": (C.c_int, [_P, C.c_int64, C.c_int, _D, C.c_double, C.c_double, _I, _D, _I, _D]),
     "sphx_hydro_update": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _I] + [_D] * 9 + [C.c_int] + [_D] * 7),
     "sphx_density": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _I, C.c_double, _D]),
@@ -160,6 +162,9 @@ class Context:
 
     def set_tuning(self, rscale=0.0, cell_factor=0.0):
         self.check(self.lib.sphx_set_tuning(self.h, float(rscale), float(cell_factor)))
+
+    def set_incremental(self, verlet=True, rscale_build=0.0):
+        self.check(self.lib.sphx_set_incremental(self.h, 1 if verlet else 0, float(rscale_build)))
 
     def stats(self):
         s = SphxStats()

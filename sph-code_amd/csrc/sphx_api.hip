@@ -64,6 +64,8 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     default_constants(&ctx->cst);
     if (const char* e = getenv("SPHX_RSCALE")) { double v = atof(e); if (v >= 1.0) ctx->rscale = v; }
     if (const char* e = getenv("SPHX_CELL")) { double v = atof(e); if (v > 0.0) ctx->cell_factor = v; }
+    if (const char* e = getenv("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
+    if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
@@ -96,7 +98,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->csi, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F, &ctx->relv,
+                     &ctx->Pi, &ctx->Bw, &ctx->csi, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F, &ctx->relv,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -126,6 +128,16 @@ extern "C" int sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor)
         ctx->rscale = rscale;
     }
     if (cell_factor > 0.0) ctx->cell_factor = cell_factor;
+    return SPHX_OK;
+}
+extern "C" int sphx_set_incremental(sphx_ctx* ctx, int verlet, double rscale_build) {
+    if (!ctx) return SPHX_E_ARG;
+    ctx->use_verlet = verlet != 0;
+    if (!ctx->use_verlet) ctx->list_valid = false;
+    if (rscale_build > 0.0) {
+        if (rscale_build < 1.0) return sphx_set_err(ctx, SPHX_E_ARG, "rscale_build %g < 1", rscale_build);
+        ctx->rscale_build = rscale_build;
+    }
     return SPHX_OK;
 }
 extern "C" int sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c) {
@@ -296,6 +308,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->n = n;
     ctx->npad = sphx_pad64(n);
     ctx->has_state = true;
+    ctx->list_valid = false;
     ctx->step_count = 0;
     ctx->dt_last = 0.0;
     return SPHX_OK;
@@ -308,32 +321,62 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238
     SPHX_TRY(sphx_clamp(ctx, n, ctx->st));
-    // cell size from the previous step's mean h (read back together with the bounding box)
-    double cell_hint = 0.0;
-    if (ctx->step_count > 0) {
-        HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, sizeof(double),
-                              hipMemcpyDeviceToHost, ctx->stream));
+    SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * ctx->npad * sizeof(int)));
+    // ---- incremental exact kNN from the Verlet lists (sphx_refresh.hip) ---------------------
+    bool searched = false;
+    if (ctx->use_verlet && ctx->list_valid && ctx->list_n == n && ctx->list_k == k) {
+        StateArrays& r = ctx->st;
+        HIPCHK(hipEventRecord(ev[1], ctx->stream));
+        int64_t nfail = 0;
+        SPHX_TRY(sphx_knn_refresh(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(),
+                                  ctx->nbr.as<int>(), r.hprev.as<double>(), &nfail));
+        if (nfail == 0) {
+            searched = true;
+            ctx->stats.refresh_steps++;
+        } else {
+            ctx->list_valid = false;         // some result could not be proven exact: rebuild
+        }
     }
-    {
-        StateArrays& s = ctx->st;
-        // sphx_build_grid synchronises the stream (bounding-box read-back)
+    if (!searched) {
+        // cell size from the previous step's mean h (read back together with the bounding box)
+        double cell_hint = 0.0;
         if (ctx->step_count > 0) {
+            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, sizeof(double),
+                                  hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             double hmean = *(double*)((char*)ctx->pinned + 256) / (double)n;
             if (hmean > 0.0 && isfinite(hmean)) cell_hint = ctx->cell_factor * hmean;
         }
-        SPHX_TRY(sphx_build_grid(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), cell_hint));
+        {
+            StateArrays& r = ctx->st;       // sphx_build_grid synchronises (bounding-box read-back)
+            SPHX_TRY(sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint));
+        }
+        SPHX_TRY(sphx_permute_state(ctx, n));
+        HIPCHK(hipEventRecord(ev[1], ctx->stream));
+        StateArrays& r = ctx->st;
+        KnnOut o;
+        o.nbr = ctx->nbr.as<int>();
+        o.h_sorted = r.hprev.as<double>();   // read as the search-radius hint, then overwritten
+        o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr; o.h_by_id = nullptr;
+        double rs = ctx->rscale;
+        if (ctx->use_verlet) {
+            SPHX_TRY(sphx_ensure(ctx, ctx->list64, (size_t)n * 64 * sizeof(int)));
+            SPHX_TRY(sphx_ensure(ctx, ctx->dref, (size_t)n * sizeof(double)));
+            o.list64 = ctx->list64.as<int>();
+            o.dref = ctx->dref.as<double>();
+            rs = ctx->rscale_build;          // wider: the list must hold 64 entries to earn its margin
+        }
+        SPHX_TRY(sphx_knn(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), r.id.as<int>(),
+                          ctx->inv.as<int>(), r.hprev.as<double>(), rs, dist, o));
+        if (ctx->use_verlet) {
+            SPHX_TRY(sphx_save_list_positions(ctx, n, r.x.as<double>(), r.y.as<double>(), r.z.as<double>()));
+            ctx->list_valid = true;
+            ctx->list_n = n;
+            ctx->list_k = k;
+        }
+        ctx->stats.rebuild_steps++;
     }
-    SPHX_TRY(sphx_permute_state(ctx, n));
-    HIPCHK(hipEventRecord(ev[1], ctx->stream));
     StateArrays& s = ctx->st;
-    SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * ctx->npad * sizeof(int)));
-    KnnOut o;
-    o.nbr = ctx->nbr.as<int>();
-    o.h_sorted = s.hprev.as<double>();       // read as the search-radius hint, then overwritten
-    o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr; o.h_by_id = nullptr;
-    SPHX_TRY(sphx_knn(ctx, n, k, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), s.id.as<int>(),
-                      ctx->inv.as<int>(), s.hprev.as<double>(), ctx->rscale, dist, o));
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
     SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,

@@ -83,6 +83,12 @@ struct sphx_ctx {
     int k = 0, s = 0;
     DevBuf rec1, recv;            // RecA[n], RecB[n]
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
+    // ---- Verlet refresh (sphx_refresh.hip) ----
+    DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current
+    bool list_valid = false, use_verlet = false;   // opt-in (sphx_set_incremental): pays only for slow drift
+    int64_t list_n = 0;
+    int list_k = 0;
+    double rscale_build = 1.3;          // search radius factor on list-building steps
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
     const int* map_perm = nullptr;  // device API: sorted -> caller index (nullptr: identity)
     int map_nactive = 0;            // device API: callers' particles below this are computed
@@ -138,6 +144,8 @@ enum {
     SC_CAND = 2,      // u64: candidate evaluations
     SC_RETRY = 3,     // u64: retried searches
     SC_HSUM = 4,      // f64: sum of h (for the next grid's cell size)
+    SC_DISP2 = 5,     // u64: bits of the max squared displacement since the Verlet list was built
+    SC_NFAIL = 6,     // u64: particles whose refreshed kNN could not be proven exact
     SC_NSLOTS = 16
 };
 
@@ -150,6 +158,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
 // knn
 struct KnnOut {
     int32_t* nbr;       // [k][npad] sorted indices (nullable)
+    int32_t* list64 = nullptr;   // [n][64] Verlet candidate list (nullable)
+    double* dref = nullptr;      // [n] exclusion radius of list64 (nullable)
     double* h_sorted;   // [n] in sorted order (nullable)
     int64_t* idx64;     // (n,k) by id (nullable)
     double* dist;       // (n,k) by id (nullable)
@@ -183,3 +193,7 @@ int sphx_scatter_rows_by_id(sphx_ctx* ctx, int64_t n, int w, const int* id, cons
 int sphx_gather3(sphx_ctx* ctx, int64_t n, const int* perm, const double* x, const double* y,
                  const double* z, double* xs, double* ys, double* zs);
 int sphx_iota(sphx_ctx* ctx, int64_t n, int* out);
+// Verlet refresh (sphx_refresh.hip)
+int sphx_knn_refresh(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y, const double* z,
+                     int32_t* nbr, double* h_sorted, int64_t* nfail_out);
+int sphx_save_list_positions(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z);

@@ -11,7 +11,7 @@
 //     accumulated does the wave pay for a 64-key bitonic sort + merge;
 //   * the search radius is per particle (previous h, or a cell-count density estimate); if
 //     fewer than K candidates lie inside it the same wave enlarges the radius and repeats, so
-//     the result is always the exact kNN (ties broken by particle id).
+//     the result is always the exact kNN (ties broken by position in the deterministic cell order).
 // Distances are accumulated as ((dx*dx + dy*dy) + dz*dz) without FMA contraction, the same
 // arithmetic SciPy's cKDTree uses, so orderings agree with the oracle bit for bit.
 #include "sphx_internal.h"
@@ -19,7 +19,6 @@
 
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
-#define KNN_INF 0x7FF0000000000000ull
 #define KNN_MAX_TRIES 48
 
 struct KnnArgs {
@@ -35,6 +34,8 @@ struct KnnArgs {
     double rscale;
     double rbound;
     int* nbr;
+    int* list64;               // [n][64] the full sorted candidate set kept per particle (nullable)
+    double* dref;              // [n] every particle NOT in list64[i] was farther than dref[i] (nullable)
     double* h_sorted;
     long long* idx64;
     double* dist;
@@ -43,96 +44,7 @@ struct KnnArgs {
     u64* counters;
 };
 
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ bool kv_less(u64 ka, u32 va, u64 kb, u32 vb) {
-    return ka < kb || (ka == kb && va < vb);
-}
-
-// ---- lane exchange lane ^ J without the LDS crossbar where the ISA allows it -----------------
-// DPP quad_perm / row_ror / row_half_mirror move data inside a row of 16 lanes in the VALU;
-// xor 16 uses ds_swizzle (no address VGPR), xor 32 the gfx950 v_permlane32_swap.
-template <int J> __device__ __forceinline__ u32 xchg32(u32 v) {
-    if constexpr (J == 1) {
-        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-    } else if constexpr (J == 2) {
-        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-    } else if constexpr (J == 4) {
-        int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);        // row_half_mirror: ^7
-        return (u32)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]: ^3
-    } else if constexpr (J == 8) {
-        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);    // row_ror:8
-    } else if constexpr (J == 16) {
-        return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                      // bitmode xor 0x10
-    } else {
-        return (u32)__shfl_xor((int)v, 32, 64);
-    }
-}
-
-// compare-exchange with lane ^ J; keep_min: this lane keeps the smaller of the pair.
-// All (key,id) pairs are distinct except the (INF, ~0) padding, for which either choice is
-// the same value, so one lexicographic compare decides both directions.
-template <int J> __device__ __forceinline__ void cmpx(u64& k, u32& v, bool keep_min) {
-    const u32 plo = xchg32<J>((u32)k), phi = xchg32<J>((u32)(k >> 32));
-    const u64 pk = ((u64)phi << 32) | plo;
-    const u32 pv = xchg32<J>(v);
-    const bool p_lt = kv_less(pk, pv, k, v);
-    const bool take = (p_lt == keep_min);
-    k = take ? pk : k;
-    v = take ? pv : v;
-}
-
-template <int SIZE, int J> __device__ __forceinline__ void sort_stage(u64& k, u32& v, int lane, bool desc) {
-    const bool up = (((lane & SIZE) == 0) != desc);
-    const bool lower = (lane & J) == 0;
-    cmpx<J>(k, v, lower == up);
-    if constexpr (J > 1) sort_stage<SIZE, J / 2>(k, v, lane, desc);
-}
-template <int SIZE> __device__ __forceinline__ void sort_sizes(u64& k, u32& v, int lane, bool desc) {
-    if constexpr (SIZE > 2) sort_sizes<SIZE / 2>(k, v, lane, desc);
-    sort_stage<SIZE, SIZE / 2>(k, v, lane, desc);
-}
-// full bitonic sort of 64 (key,id) pairs across the wave; descending if desc
-__device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
-    sort_sizes<64>(k, v, lane, desc);
-}
-template <int J> __device__ __forceinline__ void merge_stage(u64& k, u32& v, int lane) {
-    cmpx<J>(k, v, (lane & J) == 0);
-    if constexpr (J > 1) merge_stage<J / 2>(k, v, lane);
-}
-// merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
-__device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
-    sort64(ck, cv, lane, true);
-    if (kv_less(ck, cv, bk, bv)) { bk = ck; bv = cv; }   // bitonic: min of asc and desc
-    merge_stage<32>(bk, bv, lane);
-}
-
-// ---- 32-bit network: the common case -------------------------------------------------------
-// Staged survivors sit in LDS; their order is found on a UNIQUE 32-bit key
-//     (monotone 26-bit quantisation of d2 / R^2) << 6 | staging slot
-// so one exchange + v_min/v_max/v_cndmask does a compare-exchange (vs 3 exchanges + 3 compares
-// + 3 selects on (u64,u32)).  The full (d2 bits, index) pairs are then fetched from LDS by
-// slot.  Two survivors in the same quantisation bin (about 1 particle in 40 000) are put into
-// their exact order by a few odd-even steps with the full compare.
-template <int J> __device__ __forceinline__ void cmpx32(u32& k, bool keep_min) {
-    const u32 p = xchg32<J>(k);
-    const u32 mn = k < p ? k : p, mx = k < p ? p : k;
-    k = keep_min ? mn : mx;
-}
-template <int SIZE, int J> __device__ __forceinline__ void sort32_stage(u32& k, int lane) {
-    const bool up = (lane & SIZE) == 0;
-    const bool lower = (lane & J) == 0;
-    cmpx32<J>(k, lower == up);
-    if constexpr (J > 1) sort32_stage<SIZE, J / 2>(k, lane);
-}
-template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lane) {
-    if constexpr (SIZE > 2) sort32_sizes<SIZE / 2>(k, lane);
-    sort32_stage<SIZE, SIZE / 2>(k, lane);
-}
+#include "sphx_wave.h"
 
 // Sort the `cnt` staged entries at ring position `head` ascending by (key, index) into (ck, cv);
 // lanes >= cnt get the (INF, ~0) padding.  r2 = trial radius^2 bounds every staged key.
@@ -191,22 +103,6 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
     return (int)t;
 }
 
-// broadcast lane `src` (wave-uniform) of a double / int to the whole wave through SGPRs
-__device__ __forceinline__ double bcast_f64(double v, int src) {
-    const long long b = __double_as_longlong(v);
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, src);
-    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)b >> 32), src);
-    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
-}
-
-__device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
-#pragma clang fp contract(off)
-    double s = dx * dx;
-    s = s + dy * dy;
-    s = s + dz * dz;
-    return s;
-}
-
 #ifndef KNN_MIN_WAVES
 #define KNN_MIN_WAVES 6      // waves per SIMD the register budget is held to (6 -> <= 80 VGPRs; measured fastest)
 #endif
@@ -223,6 +119,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     const int base = xcd_block(blockIdx.x, gridDim.x) * KNN_PPB;
     const GridParams g = a.g;
     const int K = a.k;
+    const int KT = a.list64 ? 64 : K;
     u64* skey = stg_key[wave];
     u32* sid = stg_id[wave];
     u64 ncand = 0, nretry = 0;
@@ -282,7 +179,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         u64 bk;
         u32 bv;
         int tries = 0;
-        bool done;
+        bool done, saw_all = false;
         do {
             bk = KNN_INF;
             bv = 0xFFFFFFFFu;
@@ -382,8 +279,10 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                                 bk = ck; bv = cv;
                                 have_best = true;
                             }
-                            u64 kth = __shfl(bk, K - 1, 64);
-                            u32 kthv = __shfl(bv, K - 1, 64);
+                            // running threshold: the K-th best - or the 64th when the whole register
+                            // set is kept as a Verlet list, which must then be exact to its last entry
+                            u64 kth = __shfl(bk, KT - 1, 64);
+                            u32 kthv = __shfl(bv, KT - 1, 64);
                             if (kth != KNN_INF) { tk = kth; tv = kthv; }
                         }
                     }
@@ -405,6 +304,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             // the sphere contains the whole grid box: every particle has been a candidate
             const double gx = g.cell * g.nx, gy = g.cell * g.ny, gz = g.cell * g.nz;
             const bool covers = !(R2 < gx * gx + gy * gy + gz * gz);
+            saw_all = covers;
             done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
             if (ABL != 0) done = true;    // timing experiments never retry
             if (!done) {
@@ -424,6 +324,14 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             if (a.nbr) tile[lane][li] = valid ? (int)bv : -1;
             if (a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
             if (a.dist) a.dist[(long long)oid * K + lane] = d;
+        }
+        if (a.list64) {
+            // Verlet list for sphx_refresh.hip: the 64 nearest inside the final radius R.  Anything
+            // not listed was farther than the 64th entry (list full) or than R (list not full).
+            a.list64[(size_t)i * 64 + lane] = (bk != KNN_INF) ? (int)bv : -1;
+            const u64 k63 = __shfl(bk, 63, 64);
+            if (lane == 0)
+                a.dref[i] = saw_all ? 1e300 : (k63 != KNN_INF ? sqrt(__longlong_as_double((long long)k63)) : R);
         }
         if (lane == 0) {
             if (a.h_sorted) a.h_sorted[i] = hval;
@@ -463,6 +371,8 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.rscale = rscale;
     a.rbound = (rbound > 0.0) ? rbound : INFINITY;
     a.nbr = out.nbr;
+    a.list64 = out.list64;
+    a.dref = out.dref;
     a.h_sorted = out.h_sorted;
     a.idx64 = (long long*)out.idx64;
     a.dist = out.dist;
@@ -472,7 +382,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     int blocks = (int)(sphx_pad64(n) / KNN_PPB);
     if (const char* e = getenv("SPHX_KNN_ABL")) {       // timing experiment, results discarded
         KnnArgs b = a;
-        b.nbr = nullptr; b.h_sorted = nullptr; b.idx64 = nullptr; b.dist = nullptr; b.nontriv = nullptr;
+        b.nbr = nullptr; b.list64 = nullptr; b.dref = nullptr; b.h_sorted = nullptr; b.idx64 = nullptr; b.dist = nullptr; b.nontriv = nullptr;
         b.h_by_id = nullptr; b.counters = nullptr;
         const int mode = atoi(e);
         hipEvent_t e0, e1;

@@ -1,0 +1,116 @@
+// sphx_wave.h - wave64 building blocks shared by the search kernels: lane exchanges without the
+// LDS crossbar where the ISA allows it, bitonic networks on (u64 key, u32 index) pairs and on
+// unique 32-bit keys, SGPR broadcasts, SciPy-compatible squared distance.
+#pragma once
+#include "sphx_internal.h"
+
+#define KNN_INF 0x7FF0000000000000ull
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ bool kv_less(u64 ka, u32 va, u64 kb, u32 vb) {
+    return ka < kb || (ka == kb && va < vb);
+}
+
+// ---- lane exchange lane ^ J without the LDS crossbar where the ISA allows it -----------------
+// DPP quad_perm / row_ror / row_half_mirror move data inside a row of 16 lanes in the VALU;
+// xor 16 uses ds_swizzle (no address VGPR), xor 32 the gfx950 v_permlane32_swap.
+template <int J> __device__ __forceinline__ u32 xchg32(u32 v) {
+    if constexpr (J == 1) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);        // row_half_mirror: ^7
+        return (u32)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]: ^3
+    } else if constexpr (J == 8) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);    // row_ror:8
+    } else if constexpr (J == 16) {
+        return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                      // bitmode xor 0x10
+    } else {
+        return (u32)__shfl_xor((int)v, 32, 64);
+    }
+}
+
+// compare-exchange with lane ^ J; keep_min: this lane keeps the smaller of the pair.
+// All (key,id) pairs are distinct except the (INF, ~0) padding, for which either choice is
+// the same value, so one lexicographic compare decides both directions.
+template <int J> __device__ __forceinline__ void cmpx(u64& k, u32& v, bool keep_min) {
+    const u32 plo = xchg32<J>((u32)k), phi = xchg32<J>((u32)(k >> 32));
+    const u64 pk = ((u64)phi << 32) | plo;
+    const u32 pv = xchg32<J>(v);
+    const bool p_lt = kv_less(pk, pv, k, v);
+    const bool take = (p_lt == keep_min);
+    k = take ? pk : k;
+    v = take ? pv : v;
+}
+
+template <int SIZE, int J> __device__ __forceinline__ void sort_stage(u64& k, u32& v, int lane, bool desc) {
+    const bool up = (((lane & SIZE) == 0) != desc);
+    const bool lower = (lane & J) == 0;
+    cmpx<J>(k, v, lower == up);
+    if constexpr (J > 1) sort_stage<SIZE, J / 2>(k, v, lane, desc);
+}
+template <int SIZE> __device__ __forceinline__ void sort_sizes(u64& k, u32& v, int lane, bool desc) {
+    if constexpr (SIZE > 2) sort_sizes<SIZE / 2>(k, v, lane, desc);
+    sort_stage<SIZE, SIZE / 2>(k, v, lane, desc);
+}
+// full bitonic sort of 64 (key,id) pairs across the wave; descending if desc
+__device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
+    sort_sizes<64>(k, v, lane, desc);
+}
+template <int J> __device__ __forceinline__ void merge_stage(u64& k, u32& v, int lane) {
+    cmpx<J>(k, v, (lane & J) == 0);
+    if constexpr (J > 1) merge_stage<J / 2>(k, v, lane);
+}
+// merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
+__device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
+    sort64(ck, cv, lane, true);
+    if (kv_less(ck, cv, bk, bv)) { bk = ck; bv = cv; }   // bitonic: min of asc and desc
+    merge_stage<32>(bk, bv, lane);
+}
+
+// ---- 32-bit network: the common case -------------------------------------------------------
+// Staged survivors sit in LDS; their order is found on a UNIQUE 32-bit key
+//     (monotone 26-bit quantisation of d2 / R^2) << 6 | staging slot
+// so one exchange + v_min/v_max/v_cndmask does a compare-exchange (vs 3 exchanges + 3 compares
+// + 3 selects on (u64,u32)).  The full (d2 bits, index) pairs are then fetched from LDS by
+// slot.  Two survivors in the same quantisation bin (about 1 particle in 40 000) are put into
+// their exact order by a few odd-even steps with the full compare.
+template <int J> __device__ __forceinline__ void cmpx32(u32& k, bool keep_min) {
+    const u32 p = xchg32<J>(k);
+    const u32 mn = k < p ? k : p, mx = k < p ? p : k;
+    k = keep_min ? mn : mx;
+}
+template <int SIZE, int J> __device__ __forceinline__ void sort32_stage(u32& k, int lane) {
+    const bool up = (lane & SIZE) == 0;
+    const bool lower = (lane & J) == 0;
+    cmpx32<J>(k, lower == up);
+    if constexpr (J > 1) sort32_stage<SIZE, J / 2>(k, lane);
+}
+template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lane) {
+    if constexpr (SIZE > 2) sort32_sizes<SIZE / 2>(k, lane);
+    sort32_stage<SIZE, SIZE / 2>(k, lane);
+}
+
+
+// broadcast lane `src` (wave-uniform) of a double / int to the whole wave through SGPRs
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, src);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)b >> 32), src);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+__device__ __forceinline__ double dist2_nofma(double dx, double dy, double dz) {
+#pragma clang fp contract(off)
+    double s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+

@@ -14,8 +14,10 @@ from ._lib import dp, f64
 
 
 class Simulation:
-    def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None):
+    def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
+                 incremental=False):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
+        self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
         self.dist = 0.0 if dist is None or not np.isfinite(dist) else float(dist)
         self.first = True

@@ -197,6 +197,27 @@ def test_step_trajectory_vs_oracle(workload):
     np.testing.assert_allclose(got["T"], ref["T"], rtol=1e-9)
 
 
+def test_incremental_search_is_exact():
+    """Verlet-list refresh (sphx_refresh.hip): with a small fixed dt most steps take the kNN from
+    the candidate lists; the trajectory must be bit-identical to the full search every step."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K, nsteps = 30000, 40, 12
+    s0 = ics.polytrope_sphere(n, light=True)
+    dt = 0.02 * ics.cfl_dt(s0, K)                      # drift << h per step
+    a = Simulation(s0, n_neigh=K, incremental=False)
+    b = Simulation(s0, n_neigh=K, incremental=True)
+    for _ in range(nsteps):
+        a.step(1, fixed_dt=dt)
+        b.step(1, fixed_dt=dt)
+    ra, rb = a.download(), b.download()
+    for key in ("points", "velocities", "sizes", "densities", "E_internal"):
+        assert np.array_equal(ra[key], rb[key]), key
+    st = b.stats()
+    assert st["refresh_steps"] >= nsteps // 2, st        # the shortcut was actually taken
+    assert st["refresh_steps"] + st["rebuild_steps"] == nsteps
+
+
 def test_ingest_bit_identical():
     """positions/velocities bit-identical on ingest (upload -> download without stepping)."""
     import sph_code_amd.ics as ics
