@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* 
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncells) return;
     const int s = cell_start[c], e = cell_start[c + 1];
+    if (e - s > 512) return;      // pathologically crowded cell: leave arrival order (still a valid
+                                  // cell list; only run-to-run tie-breaking is lost) rather than O(n^2)
     for (int i = s + 1; i < e; ++i) {
         const int v = perm[i];
         int j = i - 1;

@@ -189,14 +189,23 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             u64 tk = (u64)__double_as_longlong(R * R);
             u32 tv = at_bound ? 0u : 0xFFFFFFFFu;
             const double R2 = R * R;
-            const int cy0 = cell_coord(yi - R, g.ymin, g.inv_cell, g.ny - 1);
-            const int cy1 = cell_coord(yi + R, g.ymin, g.inv_cell, g.ny - 1);
-            const int cz0 = cell_coord(zi - R, g.zmin, g.inv_cell, g.nz - 1);
-            const int cz1 = cell_coord(zi + R, g.zmin, g.inv_cell, g.nz - 1);
+            // Query position and radius in CELL units: fp64 once, then all range geometry in fp32.
+            // Every fp32 quantity is padded (radius x(1+1e-5) + 2e-3 cells, distances - 1e-3 cells;
+            // fp32 resolves 1.2e-4 cells at index 2047), so the clipped ranges can only grow: a
+            // superset of the exact fp64 ranges, never a lost neighbour.
+            const float fx = (float)((xi - g.xmin) * g.inv_cell);
+            const float fy = (float)((yi - g.ymin) * g.inv_cell);
+            const float fz = (float)((zi - g.zmin) * g.inv_cell);
+            const float Rc = (float)(R * g.inv_cell) * 1.00001f + 2e-3f;
+            const float nx1 = (float)(g.nx - 1), ny1 = (float)(g.ny - 1), nz1 = (float)(g.nz - 1);
+            const int cy0 = (int)fminf(fmaxf(fy - Rc, 0.0f), ny1);
+            const int cy1 = (int)fminf(fmaxf(fy + Rc, 0.0f), ny1);
+            const int cz0 = (int)fminf(fmaxf(fz - Rc, 0.0f), nz1);
+            const int cz1 = (int)fminf(fmaxf(fz + Rc, 0.0f), nz1);
             const int ysp = cy1 - cy0 + 1;
             const int nrows = ysp * (cz1 - cz0 + 1);
             const float inv_ysp = 1.0f / (float)ysp;
-            const double slack = 1e-9 * g.cell;
+            const float Rc2 = Rc * Rc;
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
             bool have_best = false;           // best[] still empty: first flush is a plain sort
 
@@ -207,21 +216,21 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 if (r < nrows) {
                     const int rz = (nrows <= 65536) ? (int)(((float)r + 0.5f) * inv_ysp) : r / ysp;
                     const int cy = cy0 + (r - rz * ysp), cz = cz0 + rz;
-                    // distance from the particle to the row's (y,z) cell column.  Boundary cells are
-                    // half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
-                    const double ylo = g.ymin + (double)cy * g.cell, zlo = g.zmin + (double)cz * g.cell;
-                    double dy = 0.0, dz = 0.0;
-                    if (cy > 0) dy = fmax(dy, ylo - yi);
-                    if (cy < g.ny - 1) dy = fmax(dy, yi - (ylo + g.cell));
-                    if (cz > 0) dz = fmax(dz, zlo - zi);
-                    if (cz < g.nz - 1) dz = fmax(dz, zi - (zlo + g.cell));
-                    dy = fmax(dy - slack, 0.0);
-                    dz = fmax(dz - slack, 0.0);
-                    const double rem = R2 - (dy * dy + dz * dz);
-                    if (rem >= 0.0) {         // the row meets the sphere: chord along x
-                        const double half = sqrt(rem) * (1.0 + 1e-12) + slack;
-                        const int rx0 = cell_coord(xi - half, g.xmin, g.inv_cell, g.nx - 1);
-                        const int rx1 = cell_coord(xi + half, g.xmin, g.inv_cell, g.nx - 1);
+                    // distance (in cells) from the query to the row's (y,z) cell column.  Boundary cells
+                    // are half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
+                    const float cyf = (float)cy, czf = (float)cz;
+                    float dy = 0.0f, dz = 0.0f;
+                    if (cy > 0) dy = fmaxf(dy, cyf - fy);
+                    if (cy < g.ny - 1) dy = fmaxf(dy, fy - (cyf + 1.0f));
+                    if (cz > 0) dz = fmaxf(dz, czf - fz);
+                    if (cz < g.nz - 1) dz = fmaxf(dz, fz - (czf + 1.0f));
+                    dy = fmaxf(dy - 1e-3f, 0.0f);
+                    dz = fmaxf(dz - 1e-3f, 0.0f);
+                    const float rem = Rc2 - (dy * dy + dz * dz);
+                    if (rem >= 0.0f) {        // the row meets the sphere: chord along x
+                        const float hc = sqrtf(rem) * 1.00001f + 1e-3f;
+                        const int rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
+                        const int rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
                         const int row = (cz * g.ny + cy) * g.nx;
                         s_row = a.cell_start[row + rx0];
                         cnt = a.cell_start[row + rx1 + 1] - s_row;
