@@ -20,55 +20,85 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// partial[block][6] = {xmin,ymin,zmin,xmax,ymax,zmax}; NaN coordinates are ignored (fmin/fmax)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// partial[block][13] = {min xyz, max xyz, sum xyz, sum of squares xyz, count}; non-finite
+// coordinates are ignored
+#define BB_W 13
 __global__ __launch_bounds__(RED_BLOCK) void bbox_partial(int n, const double* x, const double* y,
                                                           const double* z, double* partial) {
-    __shared__ double sm[RED_BLOCK / 64][6];
+    __shared__ double sm[RED_BLOCK / 64][BB_W];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double su[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double v[3] = {x[i], y[i], z[i]};
+        if (isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2])) {
+            cnt += 1.0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (isfinite(v[c])) { mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]); }
+            for (int c = 0; c < 3; ++c) {
+                mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]);
+                su[c] += v[c]; sq[c] += v[c] * v[c];
+            }
         }
     }
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); }
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); su[c] = wave_sum(su[c]); sq[c] = wave_sum(sq[c]);
+    }
+    cnt = wave_sum(cnt);
     if (lane == 0) {
-        for (int c = 0; c < 3; ++c) { sm[wave][c] = mn[c]; sm[wave][3 + c] = mx[c]; }
+        for (int c = 0; c < 3; ++c) {
+            sm[wave][c] = mn[c]; sm[wave][3 + c] = mx[c]; sm[wave][6 + c] = su[c]; sm[wave][9 + c] = sq[c];
+        }
+        sm[wave][12] = cnt;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
-        double v = sm[0][threadIdx.x];
+    if (threadIdx.x < BB_W) {
+        const int c = threadIdx.x;
+        double v = sm[0][c];
         for (int w = 1; w < RED_BLOCK / 64; ++w)
-            v = threadIdx.x < 3 ? fmin(v, sm[w][threadIdx.x]) : fmax(v, sm[w][threadIdx.x]);
-        partial[blockIdx.x * 6 + threadIdx.x] = v;
+            v = c < 3 ? fmin(v, sm[w][c]) : (c < 6 ? fmax(v, sm[w][c]) : v + sm[w][c]);
+        partial[blockIdx.x * BB_W + c] = v;
     }
 }
 // one wave per component: block c reduces partial[:, c]
 __global__ __launch_bounds__(64) void bbox_final(int nblocks, const double* partial, double* out) {
     const int c = blockIdx.x;
-    double v = c < 3 ? INFINITY : -INFINITY;
-    for (int b = threadIdx.x; b < nblocks; b += 64)
-        v = c < 3 ? fmin(v, partial[b * 6 + c]) : fmax(v, partial[b * 6 + c]);
-    v = c < 3 ? wave_min(v) : wave_max(v);
+    double v = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0);
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        const double p = partial[b * BB_W + c];
+        v = c < 3 ? fmin(v, p) : (c < 6 ? fmax(v, p) : v + p);
+    }
+    v = c < 3 ? wave_min(v) : (c < 6 ? wave_max(v) : wave_sum(v));
     if (threadIdx.x == 0) out[c] = v;
 }
 
+// out_minmax[0..5] = bounding box; [6..8] mean; [9..11] standard deviation; [12] finite count
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
-              double out_minmax[6]) {
+              double out_minmax[13]) {
     int blocks = (int)((n + RED_BLOCK - 1) / RED_BLOCK);
     if (blocks > RED_MAXBLOCKS) blocks = RED_MAXBLOCKS;
-    SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 1) * 6 * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 1) * BB_W * sizeof(double)));
     double* part = ctx->bbox_tmp.as<double>();
-    double* fin = part + (size_t)RED_MAXBLOCKS * 6;
+    double* fin = part + (size_t)RED_MAXBLOCKS * BB_W;
     hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, part);
-    hipLaunchKernelGGL(bbox_final, dim3(6), dim3(64), 0, ctx->stream, blocks, part, fin);
+    hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(64), 0, ctx->stream, blocks, part, fin);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx->pinned, fin, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->pinned, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(out_minmax, ctx->pinned, 6 * sizeof(double));
+    memcpy(out_minmax, ctx->pinned, BB_W * sizeof(double));
+    const double cnt = out_minmax[12] > 0.0 ? out_minmax[12] : 1.0;
+    for (int c = 0; c < 3; ++c) {
+        const double mean = out_minmax[6 + c] / cnt;
+        double var = out_minmax[9 + c] / cnt - mean * mean;
+        out_minmax[6 + c] = mean;
+        out_minmax[9 + c] = var > 0.0 ? sqrt(var) : 0.0;
+    }
     return SPHX_OK;
 }
 
@@ -191,10 +221,21 @@ __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* 
 
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint) {
-    double bb[6];
+    double bb[13];
     SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb));
+    double tmin[3], tmax[3];
     for (int c = 0; c < 3; ++c) {
         if (!(bb[3 + c] >= bb[c])) { bb[c] = 0.0; bb[3 + c] = 0.0; }   // no finite coordinate
+        tmin[c] = bb[c]; tmax[c] = bb[3 + c];
+        // Robust box: a few escaped particles (the reference lets them reach 1e11 AU, drv:233) must
+        // not stretch the grid over empty space.  The grid covers mean +- 8 sigma (a uniform or
+        // centrally condensed cloud lies entirely inside); anything beyond is clamped into the
+        // boundary cells, which the search handles exactly (half-infinite boundary cells).
+        const double lo = bb[6 + c] - 8.0 * bb[9 + c], hi = bb[6 + c] + 8.0 * bb[9 + c];
+        if (bb[9 + c] > 0.0 && hi > lo) {
+            if (bb[c] < lo) bb[c] = lo;
+            if (bb[3 + c] > hi) bb[3 + c] = hi;
+        }
     }
     double L[3];
     double Lmax = 0.0;
@@ -220,6 +261,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         cell *= 1.02 * cbrt((double)tot / (double)cap);
     }
     GridParams& g = ctx->grid;
+    (void)tmin; (void)tmax;
+    ctx->tbox = ctx->bbox_tmp.as<double>() + (size_t)RED_MAXBLOCKS * BB_W;   // bbox_final's min/max
     g.xmin = bb[0]; g.ymin = bb[1]; g.zmin = bb[2];
     g.cell = cell; g.inv_cell = 1.0 / cell;
     g.nx = nx; g.ny = ny; g.nz = nz;

@@ -52,7 +52,7 @@ struct __attribute__((aligned(32))) RecSelf { // read only by the owner's thread
 };
 
 struct GridParams {
-    double xmin, ymin, zmin;
+    double xmin, ymin, zmin;      // origin of the (robust) grid box
     double cell, inv_cell;
     int nx, ny, nz;
     int ncells;
@@ -97,6 +97,7 @@ struct sphx_ctx {
     DevBuf scal;                  // small device scalars: ct bits, dt, counters
     // ---- grid ----
     GridParams grid;
+    const double* tbox = nullptr;   // device: TRUE bounding box {min xyz, max xyz} of the last grid build
     DevBuf cell_of, cell_start, cell_fill, perm, inv, scan_tmp, bbox_tmp;
     // ---- host-API staging ----
     DevBuf in_a, in_b, in_c, in_d, in_e, in_f, in_g, in_h, in_i, in_j, out_a, out_b, out_c;
@@ -152,7 +153,7 @@ enum {
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------
 // grid
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
-              double out_minmax[6]);
+              double out_minmax[13]);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
 // knn

@@ -28,6 +28,7 @@ struct KnnArgs {
     const int* id;
     const int* inv;
     const int* cell_start;
+    const double* tbox;        // true bounding box {min xyz, max xyz}
     GridParams g;
     const double* rsearch;
     int hint_by_id;            // rsearch is indexed by id (caller order) instead of sorted order
@@ -310,9 +311,17 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             }
             const u64 kth = __shfl(bk, K - 1, 64);
             const bool full = (kth != KNN_INF);
-            // the sphere contains the whole grid box: every particle has been a candidate
-            const double gx = g.cell * g.nx, gy = g.cell * g.ny, gz = g.cell * g.nz;
-            const bool covers = !(R2 < gx * gx + gy * gy + gz * gz);
+            // the sphere contains the true bounding box of all particles (which may be much larger
+            // than the grid box when particles have escaped): every particle has been a candidate
+            // (evaluated only when the try came up short; the box is read from memory then)
+            bool covers = false;
+            if (!full) {
+                const double* tb = a.tbox;
+                const double fx2 = fmax(fabs(xi - tb[0]), fabs(xi - tb[3]));
+                const double fy2 = fmax(fabs(yi - tb[1]), fabs(yi - tb[4]));
+                const double fz2 = fmax(fabs(zi - tb[2]), fabs(zi - tb[5]));
+                covers = !(R2 < fx2 * fx2 + fy2 * fy2 + fz2 * fz2);
+            }
             saw_all = covers;
             done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
             if (ABL != 0) done = true;    // timing experiments never retry
@@ -375,6 +384,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.id = id; a.inv = inv;
     a.cell_start = ctx->cell_start.as<int>();
     a.g = ctx->grid;
+    a.tbox = ctx->tbox;
     a.rsearch = rsearch;
     a.hint_by_id = ctx->knn_hint_by_id ? 1 : 0;
     a.rscale = rscale;

@@ -139,6 +139,31 @@ def test_loop_form_d_unset_raises(nsc, golden):
         nsc.density(g["points"], g["mass"], g["particle_type"], g["nb_idx"].astype(np.int64))
 
 
+def test_neighbors_far_outliers_and_tiny_sets(nsc):
+    """Robust grid box: escaped particles (the reference lets them reach 1e11 AU, drv:233) are
+    clamped into boundary cells and must neither break exactness nor stall the search;
+    N < K returns the reference's missing-neighbour encoding (idx == N, dist 0)."""
+    from oracle import sph_oracle as orc
+    rs = np.random.RandomState(7)
+    n, K = 20000, 16
+    u = rs.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    pts = u * (rs.rand(n) ** (1 / 3.))[:, None] * 1e17
+    far = np.array([[1e22, 0, 0], [-1e22, 3e21, 0], [0, 0, 1e22], [5e21, 5e21, -5e21], [0, -1e22, 1e20]])
+    pts[:5] = far
+    idx, _, d, nontriv, h = nsc.neighbors(pts, np.inf, K)
+    oi, _, od, _, oh = orc.neighbors(pts, np.inf, K, eps=0.0)
+    np.testing.assert_allclose(d, od, rtol=2e-15, atol=0)
+    assert (np.sort(idx, axis=1) == np.sort(oi, axis=1)).all()
+    small = rs.rand(10, 3)
+    idx, _, d, nontriv, h = nsc.neighbors(small, np.inf, K)
+    assert (nontriv == 10).all() and (idx[:, 10:] == 10).all() and (d[:, 10:] == 0).all()
+    oi, _, od, ont, oh = orc.neighbors(small, np.inf, K, eps=0.0)
+    np.testing.assert_array_equal(np.sort(idx, axis=1), np.sort(oi, axis=1))
+    np.testing.assert_allclose(h, oh, rtol=2e-15)
+    one = nsc.neighbors(small[:1], np.inf, 4)
+    assert one[0][0, 0] == 0 and (one[0][0, 1:] == 1).all() and one[4][0] == 0.0
+
+
 def test_bad_arguments_raise(nsc):
     pts = np.random.RandomState(0).rand(100, 3)
     with pytest.raises(ValueError):
