@@ -36,6 +36,41 @@ template <int J> __device__ __forceinline__ u32 xchg32(u32 v) {
     }
 }
 
+// Lane patterns of the networks are compile-time constants.  Expressed as lane predicates the
+// compiler hoists 30+ of them into SGPR pairs and then spills them (2 v_readlane per use);
+// expressed as 64-bit literals they are rematerialised by s_mov where needed.
+template <int SIZE, int J, bool DESC> constexpr u64 sort_keepmin_mask() {
+    u64 m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const bool up = (((l & SIZE) == 0) != DESC);
+        const bool lower = (l & J) == 0;
+        if (lower == up) m |= (1ull << l);
+    }
+    return m;
+}
+template <int J> constexpr u64 merge_keepmin_mask() {
+    u64 m = 0;
+    for (int l = 0; l < 64; ++l)
+        if ((l & J) == 0) m |= (1ull << l);
+    return m;
+}
+// dst = MASK[lane] ? a : b with a compile-time mask: the literal is moved into VCC right at the
+// select (2 SALU), so no SGPR pair stays live for it
+template <u64 MASK> __device__ __forceinline__ u32 select_const(u32 a, u32 b) {
+    u32 d;
+    asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
+        : "=v"(d)
+        : "v"(b), "v"(a), "i"((int)(u32)(MASK & 0xFFFFFFFFull)), "i"((int)(u32)(MASK >> 32))
+        : "vcc");
+    return d;
+}
+// dst = mask[lane] ? a : b   with the mask in an SGPR pair
+__device__ __forceinline__ u32 select_mask(u64 mask, u32 a, u32 b) {
+    u32 d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
+    return d;
+}
+
 // compare-exchange with lane ^ J; keep_min: this lane keeps the smaller of the pair.
 // All (key,id) pairs are distinct except the (INF, ~0) padding, for which either choice is
 // the same value, so one lexicographic compare decides both directions.
@@ -48,11 +83,21 @@ template <int J> __device__ __forceinline__ void cmpx(u64& k, u32& v, bool keep_
     k = take ? pk : k;
     v = take ? pv : v;
 }
+// the same with the keep-min lanes given as a constant mask
+template <int J> __device__ __forceinline__ void cmpx_m(u64& k, u32& v, u64 keepmin_mask) {
+    const u32 klo = (u32)k, khi = (u32)(k >> 32);
+    const u32 plo = xchg32<J>(klo), phi = xchg32<J>(khi);
+    const u64 pk = ((u64)phi << 32) | plo;
+    const u32 pv = xchg32<J>(v);
+    const u64 lt = __builtin_amdgcn_ballot_w64(kv_less(pk, pv, k, v));
+    const u64 take = ~(lt ^ keepmin_mask);                  // take the partner's where p_lt == keep_min
+    k = ((u64)select_mask(take, phi, khi) << 32) | select_mask(take, plo, klo);
+    v = select_mask(take, pv, v);
+}
 
 template <int SIZE, int J> __device__ __forceinline__ void sort_stage(u64& k, u32& v, int lane, bool desc) {
-    const bool up = (((lane & SIZE) == 0) != desc);
-    const bool lower = (lane & J) == 0;
-    cmpx<J>(k, v, lower == up);
+    if (desc) cmpx_m<J>(k, v, sort_keepmin_mask<SIZE, J, true>());
+    else cmpx_m<J>(k, v, sort_keepmin_mask<SIZE, J, false>());
     if constexpr (J > 1) sort_stage<SIZE, J / 2>(k, v, lane, desc);
 }
 template <int SIZE> __device__ __forceinline__ void sort_sizes(u64& k, u32& v, int lane, bool desc) {
@@ -64,7 +109,7 @@ __device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
     sort_sizes<64>(k, v, lane, desc);
 }
 template <int J> __device__ __forceinline__ void merge_stage(u64& k, u32& v, int lane) {
-    cmpx<J>(k, v, (lane & J) == 0);
+    cmpx_m<J>(k, v, merge_keepmin_mask<J>());
     if constexpr (J > 1) merge_stage<J / 2>(k, v, lane);
 }
 // merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
@@ -81,15 +126,13 @@ __device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int la
 // + 3 selects on (u64,u32)).  The full (d2 bits, index) pairs are then fetched from LDS by
 // slot.  Two survivors in the same quantisation bin (about 1 particle in 40 000) are put into
 // their exact order by a few odd-even steps with the full compare.
-template <int J> __device__ __forceinline__ void cmpx32(u32& k, bool keep_min) {
+template <int J, u64 KEEPMIN> __device__ __forceinline__ void cmpx32(u32& k) {
     const u32 p = xchg32<J>(k);
     const u32 mn = k < p ? k : p, mx = k < p ? p : k;
-    k = keep_min ? mn : mx;
+    k = select_const<KEEPMIN>(mn, mx);
 }
 template <int SIZE, int J> __device__ __forceinline__ void sort32_stage(u32& k, int lane) {
-    const bool up = (lane & SIZE) == 0;
-    const bool lower = (lane & J) == 0;
-    cmpx32<J>(k, lower == up);
+    cmpx32<J, sort_keepmin_mask<SIZE, J, false>()>(k);
     if constexpr (J > 1) sort32_stage<SIZE, J / 2>(k, lane);
 }
 template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lane) {
