@@ -27,6 +27,19 @@ B_SEARCH = 24 + 4 * 40 + 8       # R pos, W idx, W h                       = 192
 B_STEP_CORE = 1248               # search + 3 passes + integrator
 
 
+def measured_traffic(n, k):
+    """HBM-side bytes per kNN launch from the committed PMC profile of this same command
+    (profiles/latest_knn_traffic.json), or None when the profile is for another size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_knn_traffic.json")) as f:
+            t = json.load(f)
+        if int(t["n"]) == int(n) and int(t["k"]) == int(k):
+            return float(t["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(workload, n_cpu, k):
     """The oracle (NumPy/SciPy restatement of the reference, oracle/sph_oracle.py) timed on this
     box's host cores on a bounded sample of the same workload: one step at n_cpu particles."""
@@ -91,8 +104,9 @@ def main():
         "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "knn_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "knn_kernel<0,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.n, args.k),
+                     "algorithmic_bytes_per_launch": B_SEARCH * args.n,
                      "algorithmic_bytes_per_particle": B_SEARCH, "kernel_ms": ms_search},
         "step_model": {"algorithmic_bytes_per_particle_step": B_STEP_CORE,
                        "achieved_GBs": B_STEP_CORE * value / 1e9,
@@ -101,7 +115,8 @@ def main():
                         ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi", "ms_visc",
                          "ms_integrate", "ms_total")},
         "search": {"candidates_per_particle_step": st["candidates"] / max(st["steps"], 1) / args.n,
-                   "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"]},
+                   "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"],
+                   "refresh_steps": st["refresh_steps"], "rebuild_steps": st["rebuild_steps"]},
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_n, args.k)
