@@ -13,6 +13,7 @@
 // cancellations such as h_j^2 - r^2 at the kernel edge reproduce the reference bit for bit.
 #pragma clang fp contract(off)
 #include <float.h>
+#include <stdlib.h>
 
 struct PrepArgs {
     int n;
@@ -122,6 +123,8 @@ __device__ __forceinline__ Q4 load4(const double* p) {
 #define NBATCH 4
 
 // ---- pass 1 ---------------------------------------------------------------------------------
+// EXP != 0: timing experiments (extra discarded launch, SPHX_PASS_EXP); 1 = half the record loads
+template <int EXP>
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                            const RecA* __restrict__ rec, double* rho_s,
                                                            OutMap om, double* rho,
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
           const double* q = reinterpret_cast<const double*>(&rec[jb[u] < 0 ? i : jb[u]]);
-          q0b[u] = load4(q); q1b[u] = load4(q + 4);
+          q0b[u] = load4(q); q1b[u] = (EXP == 1) ? q0b[u] : load4(q + 4);
       }
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
@@ -184,7 +187,29 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->nden, (size_t)n * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
-    hipLaunchKernelGGL(pass_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    if (const char* e = getenv("SPHX_PASS_EXP")) {        // timing experiment, outputs discarded
+        const int mode = atoi(e);
+        SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
+        double* d = ctx->in_j.as<double>();
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, ctx->stream));
+        if (mode == 1)
+            hipLaunchKernelGGL(pass_density_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
+                               OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
+        else
+            hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
+                               OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        fprintf(stderr, "[sphx] pass_density experiment %d: %.4f ms\n", mode, ms);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
