@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--particles", dest="n", type=int, default=1_000_000, help="particles per GPU")
     ap.add_argument("--workload", default="polytrope")
     ap.add_argument("--neigh", dest="k", type=int, default=40, help="N_NEIGH")
-    ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=400_000)
+    ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=600_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
