@@ -108,8 +108,9 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
 #endif
 // ABL != 0: timing experiments with a section removed (outputs are then meaningless and are
 // never written: the wrapper passes null output pointers); ABL == 0 is the product kernel.
-// LEAN = 1: the step loop's variant - only the K-major list and h are produced, so the API /
-// Verlet-list pointers are never loaded (17 pointers in SGPRs otherwise: measured 20 % slower).
+// LEAN = 1: the step loop's variant - only the K-major list and h (sorted order) are produced,
+// so the API / Verlet-list pointers are never loaded (17 pointers in SGPRs otherwise: measured
+// 20 % slower).  LEAN = 2: the same for the device API (h written by id).
 template <int ABL, int LEAN = 0>
 __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     __shared__ int tile[SPHX_MAX_K][KNN_PPB + 1];
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 a.dref[i] = saw_all ? 1e300 : (k63 != KNN_INF ? sqrt(__longlong_as_double((long long)k63)) : R);
         }
         if (lane == 0) {
-            if (LEAN || a.h_sorted) a.h_sorted[i] = hval;
-            if (!LEAN && a.h_by_id) a.h_by_id[oid] = hval;
+            if (LEAN == 1 || (!LEAN && a.h_sorted)) a.h_sorted[i] = hval;
+            if (LEAN == 2 || (!LEAN && a.h_by_id)) a.h_by_id[oid] = hval;
             if (!LEAN && a.nontriv) a.nontriv[oid] = found;
         }
     }
@@ -422,7 +423,10 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     }
     const bool lean = a.nbr && a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv && !a.h_by_id &&
                       a.counters;
+    const bool lean2 = a.nbr && a.h_by_id && !a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv &&
+                       a.counters;
     if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
+    else if (lean2) hipLaunchKernelGGL((knn_kernel<0, 2>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
     else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;

@@ -238,6 +238,7 @@ class DistributedSim:
         self.halo_scale = halo_scale
         self.skin_frac = skin_frac          # plan is reused while displacements stay below skin/2
         self.plan_w, self.send_idx, self.recv_counts, self.pos_plan = 0.0, None, None, None
+        self.hmax_prev, self.hmean_prev = 0.0, 0.0
         self.first = True
         self.dt_last = 0.0
         self.last = {}
@@ -271,17 +272,26 @@ class DistributedSim:
         return float(t[0])
 
     def _plan(self, widths):
-        """Send lists: my owned particles within widths[p] of region p."""
+        """Send lists: my owned particles within widths[p] of region p - all peers at once (one
+        broadcasted distance evaluation, one nonzero, one host synchronisation)."""
         pos = self.s["pos"]
-        send_idx = []
-        for p in range(self.world):
+        W = self.world
+        wt = torch.tensor(widths, dtype=torch.float64, device=pos.device)
+        lo = torch.nan_to_num(self.lo, neginf=-1e300, posinf=1e300)
+        hi = torch.nan_to_num(self.hi, neginf=-1e300, posinf=1e300)
+        d = torch.clamp(lo[None] - pos[:, None, :], min=0.) + torch.clamp(pos[:, None, :] - hi[None], min=0.)
+        mask = (d * d).sum(dim=2) <= (wt * wt)[None, :]                      # (n, W)
+        mask[:, self.rank] = False
+        pk = torch.nonzero(mask.T)                                            # sorted by peer, then particle
+        counts = torch.bincount(pk[:, 0], minlength=W).tolist() if pk.numel() else [0] * W
+        send_idx, o = [], 0
+        for p in range(W):
             if p == self.rank:
                 send_idx.append(None)
-                continue
-            d = dist_to_region(pos, self.lo[p], self.hi[p])
-            send_idx.append(torch.nonzero(d <= widths[p]).flatten())
-        counts = [0 if ix is None else int(ix.numel()) for ix in send_idx]
-        recv_counts = self.ex.counts(counts)
+            else:
+                send_idx.append(pk[o:o + counts[p], 1].contiguous())
+            o += counts[p]
+        recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
         return send_idx, recv_counts
 
     def _halo(self, send_idx, recv_counts, owned_rows):
@@ -319,7 +329,7 @@ class DistributedSim:
         s, be = self.s, self.backend
         be.clamp(s["pos"], s["vel"])                                        # drv:233-238
         no = self.n_owned
-        bootstrap = self.first or no == 0 or float(s["h"].max()) <= 0.0
+        bootstrap = self.first or no == 0 or self.hmax_prev <= 0.0
         if bootstrap:
             # a search without ghosts over-estimates every h (fewer candidates), so its maximum is
             # a rigorous halo width for the first exchange
@@ -330,7 +340,7 @@ class DistributedSim:
         else:
             d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772 if no else 0.0
             D = self._allreduce_max(d_loc)                    # bound on the displacement norm
-            hmax0 = float(s["h"].max())
+            hmax0 = self.hmax_prev
             if 2.0 * D > self.skin_frac * hmax0 or self.halo_scale * hmax0 + 2.0 * D > self.plan_w:
                 need = 1.0
             else:
@@ -342,8 +352,8 @@ class DistributedSim:
             s, no = self.s, self.n_owned                      # (a replan may have migrated particles)
             send_idx, recv_counts = self.send_idx, self.recv_counts
             ng = sum(recv_counts)
-            hint_owned = None if float(s["h"].max() if no else 0.0) <= 0.0 else s["h"]
-            mean_h = float(s["h"].mean()) if hint_owned is not None else 0.0
+            hint_owned = None if self.hmax_prev <= 0.0 else s["h"]
+            mean_h = self.hmean_prev if hint_owned is not None else 0.0
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
             owned_rows = torch.cat([s["pos"], s["vel"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
                                     s["gam"][:, None], s["ptype"][:, None], s["h"][:, None]], dim=1)
@@ -377,7 +387,13 @@ class DistributedSim:
         bw = torch.cat([bw[:no], gb[:, 0]], dim=0).contiguous()
         va, vh = be.visc(bw, m)
         # ---- dt: global minimum crossing time (nsc:786, drv:222-229) ----------------------------
-        ct_local = float(ct.reshape(-1)[0]) if torch.is_tensor(ct) else float(ct)
+        # one host synchronisation for this step's scalars: crossing time, max and mean h
+        if no:
+            ctt = ct.reshape(-1)[:1].to(h.dtype) if torch.is_tensor(ct) else torch.tensor([float(ct)], dtype=h.dtype)
+            vals = torch.cat([ctt.to(h.device), h[:no].max().reshape(1), h[:no].mean().reshape(1)]).tolist()
+        else:
+            vals = [float(ct.reshape(-1)[0]) if torch.is_tensor(ct) else float(ct), 0.0, 0.0]
+        ct_local, self.hmax_prev, self.hmean_prev = vals
         ct_min = self._allreduce_min(ct_local)
         ctv = self.DT_0 / 10. if ct_min >= HUGE_CT else ct_min + 0.0001
         if fixed_dt > 0:

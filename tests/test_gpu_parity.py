@@ -164,6 +164,41 @@ def test_neighbors_far_outliers_and_tiny_sets(nsc):
     assert one[0][0, 0] == 0 and (one[0][0, 1:] == 1).all() and one[4][0] == 0.0
 
 
+def test_neighbors_ties_duplicates_and_k_limits(nsc):
+    """Exact distance ties (regular lattice), coincident particles, K = 1 and K = 64 (the lane
+    limit).  With ties the index sets are not unique, the sorted distance rows are; two runs
+    must agree bit for bit (deterministic cell order)."""
+    from oracle import sph_oracle as orc
+    g = np.arange(12, dtype=np.float64)
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3) * 3.0e16
+    for K in (1, 27, 64):
+        idx, _, d, nontriv, h = nsc.neighbors(lat, np.inf, K)
+        oi, _, od, _, oh = orc.neighbors(lat, np.inf, K, eps=0.0)
+        np.testing.assert_allclose(d, od, rtol=2e-15, atol=0)          # distance rows are unique
+        np.testing.assert_allclose(h, oh, rtol=2e-15)
+        assert (idx[:, 0] == np.arange(len(lat))).all() and (nontriv == K).all()
+        # every reported index really is at the reported distance
+        dd = np.sqrt(((lat[idx] - lat[:, None, :]) ** 2).sum(axis=2))
+        np.testing.assert_allclose(dd, d, rtol=2e-15, atol=0)
+        idx2, _, d2, _, _ = nsc.neighbors(lat, np.inf, K)
+        assert np.array_equal(idx, idx2) and np.array_equal(d, d2)
+    rs = np.random.RandomState(11)
+    pts = rs.rand(3000, 3) * 1e17
+    pts[100:140] = pts[99]                                               # 41 coincident particles
+    idx, _, d, nontriv, h = nsc.neighbors(pts, np.inf, 16)
+    oi, _, od, _, oh = orc.neighbors(pts, np.inf, 16, eps=0.0)
+    np.testing.assert_allclose(d, od, rtol=2e-15, atol=0)
+    assert (d[99:140] == 0).all() and (h[99:140] == 0).all()
+    out = nsc.hydro_update(idx, pts, np.full(3000, 1e27), np.where(h > 0, h, 1e15), np.ones((3000, 2)),
+                           np.zeros(3000), np.full(3000, 10.), np.full(3000, 2.3), np.full(3000, 1.4),
+                           rs.normal(size=(3000, 3)) * 1e3)
+    ref = orc.hydro_update(idx, pts, np.full(3000, 1e27), np.where(h > 0, h, 1e15), np.ones((3000, 2)),
+                           np.zeros(3000), np.full(3000, 10.), np.full(3000, 2.3), np.full(3000, 1.4),
+                           rs.normal(size=(3000, 3)) * 0 + out[0] * 0)   # velocities only enter visc
+    np.testing.assert_allclose(out[3], ref[3], rtol=1e-13)
+    np.testing.assert_allclose(out[4], ref[4], rtol=1e-13)
+
+
 def test_bad_arguments_raise(nsc):
     pts = np.random.RandomState(0).rand(100, 3)
     with pytest.raises(ValueError):
