@@ -54,6 +54,43 @@ class Simulation:
         out["dt"] = dt.value
         return out
 
+    # ---- snapshot / restart and per-step diagnostics (the reference only wrote summary
+    # statistics at the end of a run, sph/code_running.py:670, and printed the mass-weighted net
+    # accelerations every step, sph/code_running.py:465-468) ----------------------------------------
+    def snapshot(self, path, state):
+        """Write a restartable particle-state snapshot (.npz): the downloaded dynamic arrays plus the
+        static per-particle arrays of `state` (mass, particle_type, mu_array, gamma_array, f_un)."""
+        d = self.download()
+        out = dict(points=d["points"], velocities=d["velocities"], total_accel=d["total_accel"],
+                   E_internal=d["E_internal"], T=d["T"], sizes=d["sizes"], dt=np.float64(d["dt"]),
+                   first=np.int64(1 if self.first else 0), n_neigh=np.int64(self.k), dist=np.float64(self.dist))
+        for key in ("mass", "particle_type", "mu_array", "gamma_array"):
+            out[key] = np.asarray(state[key], dtype=np.float64)
+        if state.get("f_un") is not None:
+            out["f_un"] = np.asarray(state["f_un"], dtype=np.float64)
+        np.savez(path, **out)
+
+    @classmethod
+    def from_snapshot(cls, path, device=None, **kw):
+        z = dict(np.load(path, allow_pickle=False))
+        state = {k_: z[k_] for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "mass",
+                                       "particle_type", "mu_array", "gamma_array")}
+        state["f_un"] = z.get("f_un")
+        sim = cls(state, n_neigh=int(z["n_neigh"]), dist=float(z["dist"]), device=device, **kw)
+        sim.first = bool(int(z["first"]))
+        return sim, state
+
+    def diagnostics(self, state):
+        """Mass-weighted net acceleration, momentum and energies of the current state
+        (sph/code_running.py:465-468 prints the first of these every step)."""
+        d = self.download()
+        m = np.asarray(state["mass"], dtype=np.float64)
+        mt = m.sum()
+        return dict(net_accel=(d["total_accel"] * m[:, None]).sum(axis=0) / mt,
+                    momentum=(d["velocities"] * m[:, None]).sum(axis=0),
+                    kinetic=0.5 * float((m * (d["velocities"] ** 2).sum(axis=1)).sum()),
+                    internal=float(d["E_internal"].sum()), dt=d["dt"])
+
     def stats(self):
         return self.ctx.stats()
 
