@@ -20,6 +20,7 @@
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
 #define KNN_MAX_TRIES 48
+#define KNN_FLAG_CAP 1024      // candidate slots per row chunk served by the flag lookup (else binary search)
 
 struct KnnArgs {
     int n, k, npad;
@@ -113,9 +114,13 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
 // 20 % slower).  LEAN = 2: the same for the device API (h written by id).
 template <int ABL, int LEAN = 0>
 __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
-    __shared__ int tile[SPHX_MAX_K][KNN_PPB + 1];
+    extern __shared__ int tile_dyn[];                 // [K][KNN_PPB + 1] result tile (sized at launch)
+#define tile(kk, li) tile_dyn[(kk) * (KNN_PPB + 1) + (li)]
     __shared__ u64 stg_key[KNN_BLOCK / 64][128];
     __shared__ u32 stg_id[KNN_BLOCK / 64][128];
+    // candidate-slot -> row lookup: one start flag per candidate slot + the compacted row bases
+    __shared__ unsigned char row_flag[KNN_BLOCK / 64][KNN_FLAG_CAP];
+    __shared__ int row_base[KNN_BLOCK / 64][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -125,6 +130,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     const int KT = (!LEAN && a.list64) ? 64 : K;
     u64* skey = stg_key[wave];
     u32* sid = stg_id[wave];
+    unsigned char* rflag = row_flag[wave];
+    int* rbase = row_base[wave];
+    for (int q = lane; q < KNN_FLAG_CAP / 4; q += 64) reinterpret_cast<u32*>(rflag)[q] = 0u;
     u64 ncand = 0, nretry = 0;
 
     // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         const int oid = __builtin_amdgcn_readlane(qid, t16);
         // wave-uniform: past the end, or a ghost (a candidate, never a query)
         if (i >= a.n || oid >= a.n_active) {
-            if (lane < K) tile[lane][li] = -1;
+            if (lane < K) tile(lane, li) = -1;
             continue;
         }
         const double xi = bcast_f64(qx, t16), yi = bcast_f64(qy, t16), zi = bcast_f64(qz, t16);
@@ -250,18 +258,41 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 ncand += (u64)T;
 
                 const int off = incl - cnt;
+                // Slot -> particle map.  Non-empty rows are compacted (rbase[ordinal] = sb) and each
+                // marks the slot where it starts; a batch then finds its rows with one flag read, one
+                // ballot and a popcount (the flags are cleared again after the chunk).  Chunks with
+                // more than KNN_FLAG_CAP slots use the 6-step shuffle search instead.
+                const bool use_flags = (T <= KNN_FLAG_CAP);
+                const bool ne = cnt > 0;
+                if (use_flags) {
+                    const u64 nem = __ballot(ne);
+                    if (ne) {
+                        rbase[__popcll(nem & ((1ull << lane) - 1ull))] = sb;
+                        rflag[off] = 1;
+                    }
+                    wave_sync();
+                }
+                int carry = 0;                // non-empty rows that started before this batch
                 for (int t0 = 0; t0 < (ABL == 2 ? 0 : T); t0 += 64) {
                     const int t = t0 + lane;
                     const bool valid = t < T;
                     const int tt = valid ? t : 0;
-                    int rr = 0;               // largest row with off[row] <= tt
+                    int p;
+                    if (use_flags) {
+                        const u64 M = __ballot(valid && rflag[tt] != 0);
+                        const int ord = carry + __popcll(M & ((2ull << lane) - 1ull)) - 1;
+                        carry += __popcll(M);
+                        p = rbase[valid ? ord : 0] + tt;
+                    } else {
+                        int rr = 0;           // largest row with off[row] <= tt
 #pragma unroll
-                    for (int st = 32; st >= 1; st >>= 1) {
-                        int pr = rr + st;
-                        int v = __shfl(off, pr, 64);
-                        if (v <= tt) rr = pr;
+                        for (int st = 32; st >= 1; st >>= 1) {
+                            int pr = rr + st;
+                            int v = __shfl(off, pr, 64);
+                            if (v <= tt) rr = pr;
+                        }
+                        p = __shfl(sb, rr, 64) + tt;
                     }
-                    const int p = __shfl(sb, rr, 64) + tt;
                     const double d2 = dist2_nofma(a.x[p] - xi, a.y[p] - yi, a.z[p] - zi);
                     const u64 key = (u64)__double_as_longlong(d2);
                     // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass.
@@ -298,6 +329,11 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                             if (kth != KNN_INF) { tk = kth; tv = kthv; }
                         }
                     }
+                }
+                if (use_flags) {              // leave the flag array clean for the next chunk
+                    wave_sync();
+                    if (ne) rflag[off] = 0;
+                    wave_sync();
                 }
             }
             if (nst > 0) {
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         const double dlast = __shfl(d, found > 0 ? found - 1 : 0, 64);
         const double hval = found > 0 ? dlast : 0.0;
         if (lane < K) {
-            if (LEAN || a.nbr) tile[lane][li] = valid ? (int)bv : -1;
+            if (LEAN || a.nbr) tile(lane, li) = valid ? (int)bv : -1;
             if (!LEAN && a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
             if (!LEAN && a.dist) a.dist[(long long)oid * K + lane] = d;
         }
@@ -363,7 +399,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         __syncthreads();
         for (int kk = wave; kk < K; kk += KNN_BLOCK / 64) {
             int i = base + lane;
-            if (i < a.npad) a.nbr[(long long)kk * a.npad + i] = tile[kk][lane];
+            if (i < a.npad) a.nbr[(long long)kk * a.npad + i] = tile(kk, lane);
         }
     }
     if (lane == 0 && a.counters) {
@@ -409,11 +445,11 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, ctx->stream));
-        if (mode == 1) hipLaunchKernelGGL((knn_kernel<1, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
-        else if (mode == 2) hipLaunchKernelGGL((knn_kernel<2, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
-        else if (mode == 3) hipLaunchKernelGGL((knn_kernel<3, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
-        else if (mode == 4) hipLaunchKernelGGL((knn_kernel<4, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
-        else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, b);
+        if (mode == 1) hipLaunchKernelGGL((knn_kernel<1, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
+        else if (mode == 2) hipLaunchKernelGGL((knn_kernel<2, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
+        else if (mode == 3) hipLaunchKernelGGL((knn_kernel<3, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
+        else if (mode == 4) hipLaunchKernelGGL((knn_kernel<4, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
+        else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
         HIPCHK(hipEventRecord(e1, ctx->stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -425,9 +461,9 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
                       a.counters;
     const bool lean2 = a.nbr && a.h_by_id && !a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv &&
                        a.counters;
-    if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
-    else if (lean2) hipLaunchKernelGGL((knn_kernel<0, 2>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), 0, ctx->stream, a);
+    if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
+    else if (lean2) hipLaunchKernelGGL((knn_kernel<0, 2>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
+    else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
