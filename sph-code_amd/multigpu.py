@@ -419,9 +419,16 @@ class DistributedSim:
         s = self.s
         owner = region_of(s["pos"], self.lo, self.hi)
         stay = owner == self.rank
-        send_idx = [None if p == self.rank else torch.nonzero(owner == p).flatten() for p in range(self.world)]
-        counts = [0 if ix is None else int(ix.numel()) for ix in send_idx]
-        recv_counts = self.ex.counts(counts)
+        leave = torch.nonzero(~stay).flatten()                 # usually a handful: group them by new owner
+        own_l = owner[leave]
+        order = torch.argsort(own_l, stable=True)
+        leave = leave[order]
+        cnt = torch.bincount(own_l, minlength=self.world).tolist() if leave.numel() else [0] * self.world
+        send_idx, o = [], 0
+        for p in range(self.world):
+            send_idx.append(None if p == self.rank else leave[o:o + cnt[p]])
+            o += cnt[p]
+        recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
         if not self.last:
             z = torch.zeros(s["pos"].shape[0], dtype=torch.float64, device=s["pos"].device)
             self.last = dict(rho=z, nden=z.clone(), visc_heat=z.clone())
