@@ -6,8 +6,10 @@ design, following SURVEY.md 8(e):
 
   * recursive coordinate bisection of the particle set into `world` axis-aligned regions with
     equal counts; a particle is OWNED by the rank whose region contains it;
-  * per step, each rank imports GHOST copies of the foreign particles lying within its halo
-    width (>= the largest kNN radius among its owned particles) of its region, searches / sums
+  * per step, each rank imports GHOST copies of the foreign particles it can need: every rank
+    publishes, on a coarse global grid, how far the search radii of its owned particles reach
+    (a dilated "need map"), and a particle is sent to every rank whose map covers its cell - so
+    the halo is as thick as the LOCAL kNN radius, thin in dense regions; the rank searches / sums
     over owned+ghost candidates for its owned particles only, and refreshes the ghosts' h_j,
     rho_j and m*Pi_j from their owners between the passes (the kernel uses the NEIGHBOUR's h
     (nsc:587-588), rho (nsc:646) and Pi (nsc:651)) - four point-to-point halo phases;
@@ -219,7 +221,7 @@ class DistributedSim:
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
     def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
-                 halo_scale=1.15, skin_frac=0.15):
+                 halo_scale=1.15, skin_frac=0.15, need_grid=96):
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
@@ -237,7 +239,19 @@ class DistributedSim:
         self.hi = torch.as_tensor(hi, dtype=torch.float64).to(self.device)
         self.halo_scale = halo_scale
         self.skin_frac = skin_frac          # plan is reused while displacements stay below skin/2
-        self.plan_w, self.send_idx, self.recv_counts, self.pos_plan = 0.0, None, None, None
+        self.w_plan, self.send_idx, self.recv_counts, self.pos_plan = None, None, None, None
+        self.grow = 1.0
+        # coarse global grid for the need maps: global bounding box of the initial state + 25 %
+        pmin = self.s["pos"].min(dim=0).values if n else torch.full((3,), 1e300, dtype=torch.float64, device=self.device)
+        pmax = self.s["pos"].max(dim=0).values if n else torch.full((3,), -1e300, dtype=torch.float64, device=self.device)
+        if world > 1:
+            t0 = pmin.to(self.comm_device); t1 = pmax.to(self.comm_device)
+            dist.all_reduce(t0, op=dist.ReduceOp.MIN); dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            pmin, pmax = t0.to(self.device), t1.to(self.device)
+        ext = torch.clamp(pmax - pmin, min=1e-300)
+        self.G = int(need_grid)
+        self.g_lo = pmin - 0.25 * ext
+        self.g_cs = float((1.5 * ext).max()) / self.G             # cubic coarse cells
         self.hmax_prev, self.hmean_prev = 0.0, 0.0
         self.first = True
         self.dt_last = 0.0
@@ -271,25 +285,38 @@ class DistributedSim:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
-    def _plan(self, widths):
-        """Send lists: my owned particles within widths[p] of region p - all peers at once (one
-        broadcasted distance evaluation, one nonzero, one host synchronisation)."""
-        pos = self.s["pos"]
+    def _coarse_cell(self, pos):
+        c = torch.floor((pos - self.g_lo[None]) / self.g_cs).to(torch.int64).clamp_(0, self.G - 1)
+        return (c[:, 2] * self.G + c[:, 1]) * self.G + c[:, 0]
+
+    def _need_map(self, w_owned):
+        """uint8 (G^3,): coarse cells from which a particle could lie within w_i of one of my owned
+        particles.  Conservative: distances are under-estimated (Chebyshev cell distance - 1)."""
+        G, cs = self.G, self.g_cs
+        wmax = torch.zeros(G * G * G, dtype=torch.float64, device=self.device)
+        if w_owned.numel():
+            wmax.scatter_reduce_(0, self._coarse_cell(self.s["pos"]), w_owned, reduce="amax", include_self=True)
+        reach = torch.where(wmax > 0, wmax + cs * 1.000001, wmax).view(1, 1, G, G, G)
+        iters = int(float(wmax.max()) / cs) + 2 if w_owned.numel() else 0
+        for _ in range(min(iters, G)):
+            reach = torch.maximum(reach, torch.nn.functional.max_pool3d(reach, 3, stride=1, padding=1) - cs)
+        return (reach.view(-1) > 0).to(torch.uint8)
+
+    def _plan(self, w_owned):
+        """Send lists from the ranks' need maps (one all_gather of G^3 bytes per rank)."""
         W = self.world
-        wt = torch.tensor(widths, dtype=torch.float64, device=pos.device)
-        lo = torch.nan_to_num(self.lo, neginf=-1e300, posinf=1e300)
-        hi = torch.nan_to_num(self.hi, neginf=-1e300, posinf=1e300)
-        d = torch.clamp(lo[None] - pos[:, None, :], min=0.) + torch.clamp(pos[:, None, :] - hi[None], min=0.)
-        mask = (d * d).sum(dim=2) <= (wt * wt)[None, :]                      # (n, W)
-        mask[:, self.rank] = False
-        pk = torch.nonzero(mask.T)                                            # sorted by peer, then particle
+        mine = self._need_map(w_owned).to(self.comm_device)
+        maps = [torch.zeros_like(mine) for _ in range(W)]
+        dist.all_gather(maps, mine)
+        maps = torch.stack(maps).to(self.device)                              # (W, G^3)
+        cell = self._coarse_cell(self.s["pos"])
+        mask = maps[:, cell] != 0                                             # (W, n)
+        mask[self.rank] = False
+        pk = torch.nonzero(mask)                                              # sorted by peer, then particle
         counts = torch.bincount(pk[:, 0], minlength=W).tolist() if pk.numel() else [0] * W
         send_idx, o = [], 0
         for p in range(W):
-            if p == self.rank:
-                send_idx.append(None)
-            else:
-                send_idx.append(pk[o:o + counts[p], 1].contiguous())
+            send_idx.append(None if p == self.rank else pk[o:o + counts[p], 1].contiguous())
             o += counts[p]
         recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
         return send_idx, recv_counts
@@ -305,55 +332,59 @@ class DistributedSim:
         return torch.zeros((0, w), dtype=torch.float64, device=owned_rows.device)
 
     # ------------------------------------------------------------------------------------------
-    def _replan(self, my_w):
-        """Migrate strays to their region's owner, then rebuild the send lists for halo width my_w
-        (+ skin).  The plan stays valid while nobody has moved more than skin/2 since (see step)."""
+    def _replan(self):
+        """Migrate strays to their region's owner, then rebuild the send lists: every owned particle
+        claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
         self._migrate()
         s = self.s
-        self.plan_w = my_w
-        widths = self._allgather_scalar(my_w)
-        self.send_idx, self.recv_counts = self._plan(widths)
+        # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
+        # (a radius changes by at most twice the local displacement, so fast movers claim more)
+        speed = torch.sqrt((s["vel"] * s["vel"]).sum(dim=1))
+        self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"],
+                                    self.halo_scale * s["h"] + speed * self.dt_last)
+        if self.world > 1:
+            self.send_idx, self.recv_counts = self._plan(self.w_plan)
+        else:
+            self.send_idx, self.recv_counts = [None], [0]
         self.pos_plan = s["pos"].clone()
         self.stats["replans"] = self.stats.get("replans", 0) + 1
 
     def step(self, fixed_dt=0.0):
         """One decomposed pass of the hot path.
 
-        Halo validity with a reused plan.  Let W be this rank's halo width when the plan was made
-        (all foreign particles within W of the region became ghosts; owned particles were inside
-        the region) and D the largest displacement of ANY particle since.  An owned particle is now
-        at most D outside the region and a foreign non-ghost is still more than W - D from it, so
-        every neighbour within h_i of an owned particle is owned or a ghost as long as
-        h_i + 2D <= W.  That is checked after every search; a failing rank widens and replans.
-        A new plan is also made as soon as 2D exceeds the skin, so the check rarely fails."""
+        Halo validity.  When the plan was made every foreign particle within w_i of owned particle
+        i became a ghost.  With D the largest displacement of ANY particle since, a foreign
+        non-ghost is still farther than w_i - 2D from i, so the neighbours within h_i of i are all
+        owned or ghosts as long as  h_i + 2D <= w_i.  That is checked for every owned particle after
+        every search; if it fails anywhere all ranks replan (with a larger factor) and redo the
+        search.  A plan is reused as long as halo_scale*h_i + 2D <= w_i holds everywhere."""
         s, be = self.s, self.backend
         be.clamp(s["pos"], s["vel"])                                        # drv:233-238
         no = self.n_owned
-        bootstrap = self.first or no == 0 or self.hmax_prev <= 0.0
+        bootstrap = self.first or self.w_plan is None or self.hmax_prev <= 0.0
         if bootstrap:
-            # a search without ghosts over-estimates every h (fewer candidates), so its maximum is
-            # a rigorous halo width for the first exchange
-            hloc = be.search(s["pos"], no, None, 0.0)
-            hmax0 = float(hloc[:no].max()) if no else 0.0
-            self._replan(hmax0 * (1.0 + self.skin_frac))
+            # a search without ghosts over-estimates every h (fewer candidates): a rigorous radius
+            # for the first exchange
+            if no:
+                s["h"] = be.search(s["pos"], no, None, 0.0)[:no].contiguous()
+            self._replan()
             D = 0.0
         else:
-            d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772 if no else 0.0
-            D = self._allreduce_max(d_loc)                    # bound on the displacement norm
-            hmax0 = self.hmax_prev
-            if 2.0 * D > self.skin_frac * hmax0 or self.halo_scale * hmax0 + 2.0 * D > self.plan_w:
-                need = 1.0
+            if no:
+                d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
             else:
-                need = 0.0
-            if self._allreduce_max(need) > 0.5:
-                self._replan((self.halo_scale + self.skin_frac) * hmax0)
+                d_loc = 0.0
+            D = self._allreduce_max(d_loc)                    # bound on the displacement norm
+            stale = float((self.halo_scale * s["h"] + 2.0 * D > self.w_plan).any()) if no else 0.0
+            if self._allreduce_max(stale) > 0.5:
+                self._replan()
                 D = 0.0
         while True:
             s, no = self.s, self.n_owned                      # (a replan may have migrated particles)
             send_idx, recv_counts = self.send_idx, self.recv_counts
             ng = sum(recv_counts)
-            hint_owned = None if self.hmax_prev <= 0.0 else s["h"]
-            mean_h = self.hmean_prev if hint_owned is not None else 0.0
+            hint_owned = s["h"]
+            mean_h = self.hmean_prev
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
             owned_rows = torch.cat([s["pos"], s["vel"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
                                     s["gam"][:, None], s["ptype"][:, None], s["h"][:, None]], dim=1)
@@ -365,12 +396,15 @@ class DistributedSim:
             gam, ptype = cat1(s["gam"], 9), cat1(s["ptype"], 10)
             hint = None if hint_owned is None else cat1(hint_owned, 11)
             h = be.search(pos, no, hint, mean_h)
-            hmax = float(h[:no].max()) if no else 0.0
-            bad = 0.0 if hmax + 2.0 * D <= self.plan_w else 1.0
+            bad = float((h[:no] + 2.0 * D > self.w_plan).any()) if no else 0.0
             if self._allreduce_max(bad) < 0.5:
                 break
-            # a kNN radius outgrew the halo somewhere: everybody replans (wider where needed)
-            self._replan(max(self.plan_w, 1.5 * hmax * (1.0 + self.skin_frac)) if bad else self.plan_w)
+            # a kNN radius outgrew its claimed reach somewhere: those particles claim their new radius
+            # (x1.5) and everybody replans
+            if no:
+                fail = h[:no] + 2.0 * D > self.w_plan
+                s["h"] = torch.where(fail, 1.5 * (h[:no] + 2.0 * D), s["h"])
+            self._replan()
             D = 0.0
             self.stats["redo"] += 1
         # ---- halo phase 2: ghosts' h_j ----------------------------------------------------------
