@@ -186,6 +186,7 @@ extern "C" int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* poi
     double *x = ctx->in_b.as<double>(), *y = ctx->in_c.as<double>(), *z = ctx->in_d.as<double>();
     double *xs = ctx->in_e.as<double>(), *ys = ctx->in_f.as<double>(), *zs = ctx->in_g.as<double>();
     SPHX_TRY(sphx_aos_to_soa3(ctx, n, ctx->in_a.as<double>(), x, y, z));
+    ctx->clip_valid = false;                 // a fresh point set: no history for the robust box
     SPHX_TRY(sphx_build_grid(ctx, n, k, x, y, z, 0.0));
     SPHX_TRY(sphx_gather3(ctx, n, ctx->perm.as<int>(), x, y, z, xs, ys, zs));
     SPHX_TRY(sphx_ensure(ctx, ctx->idx64, (size_t)n * k * sizeof(int64_t)));
@@ -309,6 +310,8 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->npad = sphx_pad64(n);
     ctx->has_state = true;
     ctx->list_valid = false;
+    ctx->clip_valid = false;
+    ctx->h_clip = 0.0;
     ctx->step_count = 0;
     ctx->dt_last = 0.0;
     return SPHX_OK;
@@ -341,11 +344,15 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         // cell size from the previous step's mean h (read back together with the bounding box)
         double cell_hint = 0.0;
         if (ctx->step_count > 0) {
-            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, sizeof(double),
+            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, 4 * sizeof(double),
                                   hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            double hmean = *(double*)((char*)ctx->pinned + 256) / (double)n;
-            if (hmean > 0.0 && isfinite(hmean)) cell_hint = ctx->cell_factor * hmean;
+            const double* hs = (const double*)((char*)ctx->pinned + 256);     // [0] sum ... [3] count
+            const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
+            if (hmean > 0.0 && isfinite(hmean)) {
+                cell_hint = ctx->cell_factor * hmean;
+                ctx->h_clip = 8.0 * hmean;
+            }
         }
         {
             StateArrays& r = ctx->st;       // sphx_build_grid synchronises (bounding-box read-back)

@@ -29,19 +29,27 @@ __device__ __forceinline__ double wave_sum(double v) {
 // partial[block][13] = {min xyz, max xyz, sum xyz, sum of squares xyz, count}; non-finite
 // coordinates are ignored
 #define BB_W 13
+struct ClipBox { double lo[3], hi[3]; int on; };
 __global__ __launch_bounds__(RED_BLOCK) void bbox_partial(int n, const double* x, const double* y,
-                                                          const double* z, double* partial) {
+                                                          const double* z, ClipBox clip, double* partial) {
     __shared__ double sm[RED_BLOCK / 64][BB_W];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     double su[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double v[3] = {x[i], y[i], z[i]};
         if (isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2])) {
-            cnt += 1.0;
+            // min/max over everything finite; mean and variance only over the clip box (the region
+            // the cloud occupied last time, doubled) so that escapers cannot drag the grid with them
+            bool in = true;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]);
-                su[c] += v[c]; sq[c] += v[c] * v[c];
+                if (clip.on && (v[c] < clip.lo[c] || v[c] > clip.hi[c])) in = false;
+            }
+            if (in) {
+                cnt += 1.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { su[c] += v[c]; sq[c] += v[c] * v[c]; }
             }
         }
     }
@@ -78,15 +86,19 @@ __global__ __launch_bounds__(64) void bbox_final(int nblocks, const double* part
     if (threadIdx.x == 0) out[c] = v;
 }
 
-// out_minmax[0..5] = bounding box; [6..8] mean; [9..11] standard deviation; [12] finite count
+// out_minmax[0..5] = bounding box of all finite points; [6..8] mean, [9..11] standard deviation,
+// [12] count - the last three over the context's clip box when it is valid (use_clip)
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
-              double out_minmax[13]) {
+              double out_minmax[13], bool use_clip) {
+    ClipBox clip;
+    clip.on = (use_clip && ctx->clip_valid) ? 1 : 0;
+    for (int c = 0; c < 3; ++c) { clip.lo[c] = ctx->clip_lo[c]; clip.hi[c] = ctx->clip_hi[c]; }
     int blocks = (int)((n + RED_BLOCK - 1) / RED_BLOCK);
     if (blocks > RED_MAXBLOCKS) blocks = RED_MAXBLOCKS;
     SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 1) * BB_W * sizeof(double)));
     double* part = ctx->bbox_tmp.as<double>();
     double* fin = part + (size_t)RED_MAXBLOCKS * BB_W;
-    hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, part);
+    hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, clip, part);
     hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(64), 0, ctx->stream, blocks, part, fin);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->pinned, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -222,7 +234,9 @@ __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* 
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint) {
     double bb[13];
-    SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb));
+    SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, true));
+    if (ctx->clip_valid && bb[12] < 0.5 * (double)n)       // the clip box lost the cloud: re-anchor
+        SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, false));
     double tmin[3], tmax[3];
     for (int c = 0; c < 3; ++c) {
         if (!(bb[3 + c] >= bb[c])) { bb[c] = 0.0; bb[3 + c] = 0.0; }   // no finite coordinate
@@ -240,6 +254,13 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     double L[3];
     double Lmax = 0.0;
     for (int c = 0; c < 3; ++c) { L[c] = bb[3 + c] - bb[c]; if (L[c] > Lmax) Lmax = L[c]; }
+    // next time, statistics are taken over this box doubled about its centre
+    for (int c = 0; c < 3; ++c) {
+        const double mid = 0.5 * (bb[c] + bb[3 + c]), half = (L[c] > 0.0 ? L[c] : Lmax);
+        ctx->clip_lo[c] = mid - half;
+        ctx->clip_hi[c] = mid + half;
+    }
+    ctx->clip_valid = (Lmax > 0.0);
     if (!(Lmax > 0.0)) Lmax = 1.0;
     double cell = cell_hint;
     if (!(cell > 0.0) || !isfinite(cell)) {

@@ -89,23 +89,34 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
     return SPHX_OK;
 }
 
-// ---- sum of h (next grid's cell size) ------------------------------------------------------
-__global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, double* out) {
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += h[i];
+// ---- clipped sum of h (next grid's cell size) -------------------------------------------------
+// Escaped particles have kNN radii many orders of magnitude above the cloud's; values above
+// `clip` (8 x the previous mean) are left out.  out[0] += sum, out[3] += count (SC_HSUM, SC_HCNT).
+__global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, double clip, double* out_sum,
+                                                   double* out_cnt) {
+    __shared__ double sm[4], sc[4];
+    double s = 0.0, c = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = h[i];
+        if (v > 0.0 && (clip <= 0.0 || v <= clip)) { s += v; c += 1.0; }
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(out_sum, sm[0] + sm[1] + sm[2] + sm[3]);
+        atomicAdd(out_cnt, sc[0] + sc[1] + sc[2] + sc[3]);
+    }
 }
 int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h) {
     double* out = ctx->scal.as<double>() + SC_HSUM;
+    double* cnt = ctx->scal.as<double>() + SC_HCNT;
     HIPCHK(hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(double), ctx->stream));
     int blocks = (int)((n + 255) / 256);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, out);
+    hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, ctx->h_clip, out, cnt);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -98,6 +98,9 @@ struct sphx_ctx {
     // ---- grid ----
     GridParams grid;
     const double* tbox = nullptr;   // device: TRUE bounding box {min xyz, max xyz} of the last grid build
+    double clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};   // statistics window of the robust grid box
+    bool clip_valid = false;
+    double h_clip = 0.0;            // h above this is left out of the mean that sizes the cells (0: none)
     DevBuf cell_of, cell_start, cell_fill, perm, inv, scan_tmp, bbox_tmp;
     // ---- host-API staging ----
     DevBuf in_a, in_b, in_c, in_d, in_e, in_f, in_g, in_h, in_i, in_j, out_a, out_b, out_c;
@@ -147,13 +150,14 @@ enum {
     SC_HSUM = 4,      // f64: sum of h (for the next grid's cell size)
     SC_DISP2 = 5,     // u64: bits of the max squared displacement since the Verlet list was built
     SC_NFAIL = 6,     // u64: particles whose refreshed kNN could not be proven exact
+    SC_HCNT = 7,      // f64: number of h values in SC_HSUM
     SC_NSLOTS = 16
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------
 // grid
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
-              double out_minmax[13]);
+              double out_minmax[13], bool use_clip);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
 // knn

@@ -424,7 +424,13 @@ class DistributedSim:
         # one host synchronisation for this step's scalars: crossing time, max and mean h
         if no:
             ctt = ct.reshape(-1)[:1].to(h.dtype) if torch.is_tensor(ct) else torch.tensor([float(ct)], dtype=h.dtype)
-            vals = torch.cat([ctt.to(h.device), h[:no].max().reshape(1), h[:no].mean().reshape(1)]).tolist()
+            ho = h[:no]
+            if self.hmean_prev > 0.0:          # escapers' radii must not size the cells (robust mean)
+                keep = ho <= 8.0 * self.hmean_prev
+                hm = (ho * keep).sum() / keep.sum().clamp(min=1)
+            else:
+                hm = ho.mean()
+            vals = torch.cat([ctt.to(h.device), ho.max().reshape(1), hm.reshape(1)]).tolist()
         else:
             vals = [float(ct.reshape(-1)[0]) if torch.is_tensor(ct) else float(ct), 0.0, 0.0]
         ct_local, self.hmax_prev, self.hmean_prev = vals

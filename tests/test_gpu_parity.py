@@ -297,6 +297,27 @@ def test_snapshot_restart_is_bit_identical(tmp_path):
     assert np.isfinite(dg["net_accel"]).all() and dg["kinetic"] > 0 and dg["internal"] > 0
 
 
+def test_runaway_particles_do_not_stall_the_search():
+    """The reference's scheme (unclipped neighbour gradient, dt >= dt_0/5) is numerically unstable on a
+    dense cloud: a few particles are flung out to the position clamp (1e11 AU, drv:233) - the CPU
+    oracle does the same.  The cell grid must keep tracking the cloud (clipped statistics), so a
+    step stays milliseconds instead of degenerating to an all-pairs scan."""
+    import time
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n = 200000
+    s0 = ics.uniform_sphere(n, radius=2.5e16 * (n / 20000.) ** (1. / 3.), light=True)   # h ~ 3e15 m
+    sim = Simulation(s0)
+    t0 = time.perf_counter()
+    sim.step(8)
+    elapsed = time.perf_counter() - t0
+    d = sim.download()
+    assert np.abs(d["points"]).max() > 1e3 * np.abs(s0["points"]).max()      # the blow-up did happen
+    assert np.isfinite(d["sizes"]).all() and np.median(d["sizes"]) < 1e17      # the bulk is still resolved
+    assert sim.stats()["cell_size"] < 1e17
+    assert elapsed < 20.0, elapsed
+
+
 def test_ingest_bit_identical():
     """positions/velocities bit-identical on ingest (upload -> download without stepping)."""
     import sph_code_amd.ics as ics
