@@ -189,6 +189,10 @@ int sphx_dev_set_mean_h(sphx_ctx* ctx, double mean_h);
  * previous h per particle or NULL; rscale <= 0: context default; h_out (n_total).          */
 int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, int k, const double* pos,
                     const double* hint, double rscale, double dist, double* h_out);
+/* cell order of the last sphx_dev_search: out[s] (int32, n_total) = caller index of the s-th
+ * particle.  A caller that re-orders its owned arrays accordingly keeps the library's gathers
+ * and scatters nearly sequential on the next step.                                            */
+int sphx_dev_get_order(sphx_ctx* ctx, int64_t n_total, int32_t* out);
 /* gather records; h must be complete (owned from sphx_dev_search, ghosts from their owners) */
 int sphx_dev_prep(sphx_ctx* ctx, const double* pos, const double* vel, const double* mass,
                   const double* h, const double* T, const double* mu, const double* gamma,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sphx_sync": (C.c_int, [_P]),
     "sphx_dev_set_mean_h": (C.c_int, [_P, C.c_double]),
     "sphx_dev_search": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_double, C.c_double, _P]),
+    "sphx_dev_get_order": (C.c_int, [_P, C.c_int64, _P]),
     "sphx_dev_prep": (C.c_int, [_P] + [_P] * 8),
     "sphx_dev_density": (C.c_int, [_P] + [_P] * 4),
     "sphx_dev_pi": (C.c_int, [_P] + [_P] * 4),

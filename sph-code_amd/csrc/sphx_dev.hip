@@ -91,6 +91,17 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     return rc;
 }
 
+// perm of the last sphx_dev_search: out[s] = caller index of the s-th particle in cell order
+extern "C" int sphx_dev_get_order(sphx_ctx* ctx, int64_t n_total, int32_t* out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(out);
+    if (!ctx->map_perm || ctx->n != n_total)
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_get_order: no search over %lld particles", (long long)n_total);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(out, ctx->map_perm, (size_t)n_total * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    return SPHX_OK;
+}
+
 extern "C" int sphx_dev_set_mean_h(sphx_ctx* ctx, double mean_h) {
     if (!ctx) return SPHX_E_ARG;
     ctx->dev_hmean = mean_h;

@@ -173,6 +173,12 @@ class LibBackend:
                                            float(self.dist_bound), self._p(h)))
         return h
 
+    def order(self, n_total):
+        """Cell order of the last search (sorted position -> caller index), int64 tensor."""
+        out = torch.empty(n_total, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.sphx_dev_get_order(self.ctx.h, n_total, self._p(out)))
+        return out.to(torch.int64)
+
     def prep(self, pos, vel, m, h, T, mu, gam, ptype):
         self._keep = (pos, vel, m, h, T, mu, gam, ptype)
         self._chk(self.lib.sphx_dev_prep(self.ctx.h, *[self._p(t) for t in self._keep]))
@@ -253,6 +259,7 @@ class DistributedSim:
         self.g_lo = pmin - 0.25 * ext
         self.g_cs = float((1.5 * ext).max()) / self.G             # cubic coarse cells
         self.hmax_prev, self.hmean_prev = 0.0, 0.0
+        self.last_ntotal = None
         self.first = True
         self.dt_last = 0.0
         self.last = {}
@@ -335,6 +342,7 @@ class DistributedSim:
     def _replan(self):
         """Migrate strays to their region's owner, then rebuild the send lists: every owned particle
         claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
+        self._reorder()
         self._migrate()
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
@@ -348,6 +356,22 @@ class DistributedSim:
             self.send_idx, self.recv_counts = [None], [0]
         self.pos_plan = s["pos"].clone()
         self.stats["replans"] = self.stats.get("replans", 0) + 1
+
+    def _reorder(self):
+        """Put the owned arrays into the cell order of the last search (when the backend exposes
+        it): the library's gathers/scatters between caller order and cell order become nearly
+        sequential, as in the fused single-GPU loop."""
+        if self.last_ntotal is None or not hasattr(self.backend, "order"):
+            return
+        no = self.n_owned
+        order = self.backend.order(self.last_ntotal)
+        order = order[order < no]
+        if order.numel() != no:
+            return
+        for key in list(self.s):
+            self.s[key] = self.s[key][order].contiguous()
+        self.last = {k_: v[order].contiguous() for k_, v in self.last.items()}
+        self.last_ntotal = None
 
     def step(self, fixed_dt=0.0):
         """One decomposed pass of the hot path.
@@ -447,6 +471,7 @@ class DistributedSim:
         s["h"] = h[:no].contiguous()
         self.last = dict(rho=rho[:no], nden=nden[:no], visc_heat=vh[:no])
         self.dt_last = dt
+        self.last_ntotal = int(pos.shape[0])
         self.first = False
         self.stats["steps"] += 1
         self.stats["ghosts"] += ng
