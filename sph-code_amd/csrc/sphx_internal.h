@@ -92,8 +92,7 @@ struct sphx_ctx {
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
     const int* map_perm = nullptr;  // device API: sorted -> caller index (nullptr: identity)
     int map_nactive = 0;            // device API: callers' particles below this are computed
-    DevBuf rho, rhod, nden, G, Pi, Bw, csi, va, vh, ha, F;
-    DevBuf relv;                  // per-particle max relative speed^2 (crossing time)
+    DevBuf rho, rhod, nden, G, Pi, Bw, va, vh, ha, F;
     DevBuf scal;                  // small device scalars: ct bits, dt, counters
     // ---- grid ----
     GridParams grid;

@@ -95,30 +95,10 @@ template <int J> __device__ __forceinline__ void cmpx_m(u64& k, u32& v, u64 keep
     v = select_mask(take, pv, v);
 }
 
-template <int SIZE, int J> __device__ __forceinline__ void sort_stage(u64& k, u32& v, int lane, bool desc) {
-    if (desc) cmpx_m<J>(k, v, sort_keepmin_mask<SIZE, J, true>());
-    else cmpx_m<J>(k, v, sort_keepmin_mask<SIZE, J, false>());
-    if constexpr (J > 1) sort_stage<SIZE, J / 2>(k, v, lane, desc);
-}
-template <int SIZE> __device__ __forceinline__ void sort_sizes(u64& k, u32& v, int lane, bool desc) {
-    if constexpr (SIZE > 2) sort_sizes<SIZE / 2>(k, v, lane, desc);
-    sort_stage<SIZE, SIZE / 2>(k, v, lane, desc);
-}
-// full bitonic sort of 64 (key,id) pairs across the wave; descending if desc
-__device__ __forceinline__ void sort64(u64& k, u32& v, int lane, bool desc) {
-    sort_sizes<64>(k, v, lane, desc);
-}
 template <int J> __device__ __forceinline__ void merge_stage(u64& k, u32& v, int lane) {
     cmpx_m<J>(k, v, merge_keepmin_mask<J>());
     if constexpr (J > 1) merge_stage<J / 2>(k, v, lane);
 }
-// merge: `best` ascending, `cand` any order -> best = 64 smallest of the union, ascending
-__device__ __forceinline__ void merge64(u64& bk, u32& bv, u64 ck, u32 cv, int lane) {
-    sort64(ck, cv, lane, true);
-    if (kv_less(ck, cv, bk, bv)) { bk = ck; bv = cv; }   // bitonic: min of asc and desc
-    merge_stage<32>(bk, bv, lane);
-}
-
 // ---- 32-bit network: the common case -------------------------------------------------------
 // Staged survivors sit in LDS; their order is found on a UNIQUE 32-bit key
 //     (monotone 26-bit quantisation of d2 / R^2) << 6 | staging slot
