@@ -18,7 +18,8 @@ __device__ __forceinline__ bool kv_less(u64 ka, u32 va, u64 kb, u32 vb) {
 
 // ---- lane exchange lane ^ J without the LDS crossbar where the ISA allows it -----------------
 // DPP quad_perm / row_ror / row_half_mirror move data inside a row of 16 lanes in the VALU;
-// xor 16 uses ds_swizzle (no address VGPR), xor 32 the gfx950 v_permlane32_swap.
+// xor 16 uses ds_swizzle (no address VGPR), xor 32 ds_bpermute (v_permlane32_swap + select
+// measured no faster).
 template <int J> __device__ __forceinline__ u32 xchg32(u32 v) {
     if constexpr (J == 1) {
         return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
