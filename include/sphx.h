@@ -161,6 +161,11 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
                       const double* mass, const double* ptype, const double* f_un,
                       const double* T, const double* mu, const double* gamma,
                       const double* E_internal, const double* accel_old);
+/* Enable the dust->gas drag of nsc.net_impulse (nsc:719-742) inside the step loop:
+ * visc_accel = drag*rho_dust/rho*[gas] + reaction + viscous accel (drv:455,462-463,473).
+ * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
+ * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
+int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
 /* One or more passes of the hot path.  k = N_NEIGH, dist = distance_upper_bound of
  * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);
  * fixed_dt > 0 overrides the crossing-time rule (drv:225-229).                           */

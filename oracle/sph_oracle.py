@@ -370,13 +370,16 @@ def clamp_state(points, velocities):
 
 
 def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type, ha, va, vh, dt,
-              grav_accel=None):
+              grav_accel=None, drag=None):
     """drv:460-491: acceleration assembly (physical sign), viscous limiter, leapfrog,
     energy.  Returns (points, velocities, total_accel, E_internal, T)."""
     gas = (np.asarray(particle_type) == 0.)[:, None]
     with np.errstate(all="ignore"):
         pressure_accel = np.nan_to_num(-ha * gas)                              # drv:460
         visc = np.nan_to_num(-va * gas)
+        if drag is not None:                                                   # drv:462-463,473
+            onto, react, rho, rho_d = drag
+            visc = np.nan_to_num(onto * (rho_d / rho)[:, None] * gas) + np.nan_to_num(react) + visc
         vn = np.sqrt(np.sum(v ** 2, axis=1)); an = np.sqrt(np.sum(visc ** 2, axis=1))
         lim = (vn - an * dt) < 0                                               # drv:475
         visc = np.where(lim[:, None], -v / dt, visc)
@@ -391,7 +394,7 @@ def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type,
 
 
 def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1,
-         fixed_dt=0.0):
+         fixed_dt=0.0, with_drag=False):
     """One pass of the hot path: search -> dt -> sums -> leapfrog update.
 
     state: dict with points, velocities, mass, particle_type, f_un, T, mu_array, gamma_array,
@@ -408,8 +411,12 @@ def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, 
         fu = np.ones((len(p), 1))
     ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, fu, s["particle_type"],
                                                    s["T"], s["mu_array"], s["gamma_array"], v)
+    drag = None
+    if with_drag:                                                              # drv:455
+        onto, react = net_impulse(p, s["mass"], h, v, s["particle_type"], nb, s["f_un"])
+        drag = (onto, react, rho, rho_d)
     p, v, total, E, T = integrate(p, v, s["total_accel"], s["E_internal"], s["mass"], s["mu_array"],
-                                  s["gamma_array"], s["particle_type"], ha, va, vh, dt, grav_accel)
+                                  s["gamma_array"], s["particle_type"], ha, va, vh, dt, grav_accel, drag)
     s.update(points=p, velocities=v, total_accel=total, E_internal=E, T=T, dt=dt, sizes=h,
              densities=rho, num_densities=nden, neighbor=nb)
     return s

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sphx_crossing_time": (C.c_int, [_P, C.c_int64, C.c_int, _I, _D, _D, _D, _D]),
     "sphx_net_impulse": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _D, _D, _I, _D, _D, _D, _D]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
+    "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),
     "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
     "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),

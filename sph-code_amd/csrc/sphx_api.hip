@@ -89,7 +89,7 @@ static void free_buf(DevBuf& b) {
 }
 static void free_state(StateArrays& s) {
     DevBuf* all[] = {&s.x, &s.y, &s.z, &s.vx, &s.vy, &s.vz, &s.ax, &s.ay, &s.az, &s.m, &s.T,
-                     &s.mu, &s.gam, &s.E, &s.hprev, &s.ptype, &s.id, &s.fun};
+                     &s.mu, &s.gam, &s.E, &s.hprev, &s.ptype, &s.id, &s.fun, &s.mgm, &s.mcs};
     for (DevBuf* b : all) free_buf(*b);
 }
 
@@ -98,7 +98,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
+                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -309,11 +309,28 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->n = n;
     ctx->npad = sphx_pad64(n);
     ctx->has_state = true;
+    ctx->drag = false;
     ctx->list_valid = false;
     ctx->clip_valid = false;
     ctx->h_clip = 0.0;
     ctx->step_count = 0;
     ctx->dt_last = 0.0;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state || ctx->step_count != 0)
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_drag must follow sphx_state_upload directly");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!mean_grain_mass || !mean_cross) { ctx->drag = false; return SPHX_OK; }
+    const size_t nb = (size_t)ctx->n * sizeof(double);
+    SPHX_TRY(sphx_ensure(ctx, ctx->st.mgm, nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->st.mcs, nb));
+    HIPCHK(hipMemcpyAsync(ctx->st.mgm.p, mean_grain_mass, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->st.mcs.p, mean_cross, nb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->drag = true;
     return SPHX_OK;
 }
 
@@ -396,6 +413,9 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
     HIPCHK(hipEventRecord(ev[5], ctx->stream));
     SPHX_TRY(sphx_pass_visc(ctx, n, k, s.m.as<double>()));
+    if (ctx->drag)
+        SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
+                                s.mcs.as<double>()));
     HIPCHK(hipEventRecord(ev[6], ctx->stream));
     SPHX_TRY(sphx_compute_dt(ctx, first, fixed_dt));
     SPHX_TRY(sphx_integrate(ctx, n));

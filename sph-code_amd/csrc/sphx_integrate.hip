@@ -42,8 +42,8 @@ int sphx_clamp(sphx_ctx* ctx, int64_t n, StateArrays& s) {
 struct GatherArgs {
     int n, narr, s;
     const int* perm;
-    const double* src[16];
-    double* dst[16];
+    const double* src[18];
+    double* dst[18];
     const int* id_src; int* id_dst; int* inv;
     const double* fun_src; double* fun_dst;
 };
@@ -74,6 +74,13 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
         SPHX_TRY(sphx_ensure(ctx, *dst[q], (size_t)n * sizeof(double)));
         g.src[q] = src[q]->as<double>();
         g.dst[q] = dst[q]->as<double>();
+    }
+    if (ctx->drag) {                          // the drag coefficients travel with the particles
+        SPHX_TRY(sphx_ensure(ctx, b.mgm, (size_t)n * sizeof(double)));
+        SPHX_TRY(sphx_ensure(ctx, b.mcs, (size_t)n * sizeof(double)));
+        g.src[16] = a.mgm.as<double>(); g.dst[16] = b.mgm.as<double>();
+        g.src[17] = a.mcs.as<double>(); g.dst[17] = b.mcs.as<double>();
+        g.narr = 18;
     }
     SPHX_TRY(sphx_ensure(ctx, b.id, (size_t)n * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
@@ -152,6 +159,7 @@ struct IntegArgs {
     double *E, *T;
     const double *m, *mu, *gam, *ptype;
     const double *ha, *va, *vh;                        // hydro_update outputs (reference sign)
+    const double *rho, *rhod, *drag_on, *drag_re;      // drag terms (drag_on == nullptr: none)
     const double* dt;
     double m_h, kB;
 };
@@ -166,6 +174,10 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     for (int c = 0; c < 3; ++c) {
         pa[c] = nan_to_num(-a.ha[3 * (size_t)i + c] * g);     // physical sign, drv:460
         vis[c] = nan_to_num(-a.va[3 * (size_t)i + c] * g);
+        if (a.drag_on) {                                      // drv:462-463,473
+            const double dg = nan_to_num(a.drag_on[3 * (size_t)i + c] * a.rhod[i] / a.rho[i] * g);
+            vis[c] = dg + nan_to_num(a.drag_re[3 * (size_t)i + c]) + vis[c];
+        }
     }
     const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     const double an = sqrt(vis[0] * vis[0] + vis[1] * vis[1] + vis[2] * vis[2]);
@@ -200,6 +212,9 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n) {
     a.m = s.m.as<double>(); a.mu = s.mu.as<double>(); a.gam = s.gam.as<double>();
     a.ptype = s.ptype.as<double>();
     a.ha = ctx->ha.as<double>(); a.va = ctx->va.as<double>(); a.vh = ctx->vh.as<double>();
+    a.rho = ctx->rho.as<double>(); a.rhod = ctx->rhod.as<double>();
+    a.drag_on = ctx->drag ? ctx->drag_on.as<double>() : nullptr;
+    a.drag_re = ctx->drag ? ctx->drag_re.as<double>() : nullptr;
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);

@@ -65,6 +65,7 @@ struct StateArrays {
     DevBuf ptype;                                // f64 0/1/2 as in the reference (drv:127)
     DevBuf id;                                   // int32 persistent particle id
     DevBuf fun;                                  // (n,s) f64 composition (optional)
+    DevBuf mgm, mcs;                             // mean grain mass / cross-section (drag, optional)
 };
 
 struct sphx_ctx {
@@ -83,6 +84,8 @@ struct sphx_ctx {
     int k = 0, s = 0;
     DevBuf rec1, recv;            // RecA[n], RecB[n]
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
+    DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
+    bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
     // ---- Verlet refresh (sphx_refresh.hip) ----
     DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current
     bool list_valid = false, use_verlet = false;   // opt-in (sphx_set_incremental): pays only for slow drift
@@ -190,6 +193,8 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n);
 int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h);
 int sphx_compute_dt(sphx_ctx* ctx, int first, double fixed_dt);
 int sphx_integrate(sphx_ctx* ctx, int64_t n);
+int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const double* ptype, const double* mgm,
+                   const double* mcs);
 int sphx_aos_to_soa3(sphx_ctx* ctx, int64_t n, const double* aos, double* x, double* y, double* z);
 int sphx_soa3_to_aos_by_id(sphx_ctx* ctx, int64_t n, const int* id, const double* x, const double* y,
                            const double* z, double* aos);

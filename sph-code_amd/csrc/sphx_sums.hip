@@ -374,6 +374,58 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     return SPHX_OK;
 }
 
+// ---- dust -> gas drag with scatter-added reaction          nsc:719-742 (net_impulse) --------------
+// Loop-form semantics inside the step loop: smoothing length of the dust neighbour (Weigh2_dust,
+// nsc:678), deltas relative to the particle itself.  The reaction is a scatter-add (float atomics):
+// with dust present the step is no longer bitwise reproducible, only to rounding.
+__global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                        const RecB* __restrict__ recb,
+                                                        const double* __restrict__ m,
+                                                        const double* __restrict__ ptype,
+                                                        const double* __restrict__ mgm,
+                                                        const double* __restrict__ mcs, double* onto,
+                                                        double* react) {
+    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* rq = reinterpret_cast<const double*>(&recb[i]);
+    const Q4 r0 = load4(rq), rv = load4(rq + 4);
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    for (int kk = 0; kk < k; ++kk) {
+        const int j = nbr[(size_t)kk * npad + i];
+        if (j < 0 || ptype[j] != 2.0) continue;                  // dust neighbours only   nsc:736
+        const double* qb = reinterpret_cast<const double*>(&recb[j]);
+        const Q4 q0 = load4(qb), qv = load4(qb + 4);
+        const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+        const double ds2 = q0.d, ds = sqrt(ds2);
+        const double q = ds2 - (dx * dx + dy * dy + dz * dz);
+        const double ds4 = ds2 * ds2;
+        const double wf = m[j] * 315.0 * (q * q * q) / (201.06192982974676 * (ds4 * ds4 * ds));   // nsc:678-681
+        if (!(wf > 0.0)) continue;
+        const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
+        const double coef = wf / mgm[j] * mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
+        const double fx = coef * dvx, fy = coef * dvy, fz = coef * dvz;
+        ox += fx; oy += fy; oz += fz;
+        if (j != i) {                                              // nsc:741
+            atomicAdd(&react[3 * (size_t)j], -fx);
+            atomicAdd(&react[3 * (size_t)j + 1], -fy);
+            atomicAdd(&react[3 * (size_t)j + 2], -fz);
+        }
+    }
+    onto[3 * (size_t)i] = ox; onto[3 * (size_t)i + 1] = oy; onto[3 * (size_t)i + 2] = oz;
+}
+
+int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const double* ptype, const double* mgm,
+                   const double* mcs) {
+    SPHX_TRY(sphx_ensure(ctx, ctx->drag_on, (size_t)n * 3 * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->drag_re, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(ctx->drag_re.p, 0, (size_t)n * 3 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(pass_drag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(), m, ptype, mgm, mcs,
+                       ctx->drag_on.as<double>(), ctx->drag_re.as<double>());
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 // ---- species pass: F[s,i] = sum_k Nw_j f_un[j,s] W       nsc:624-627 -------------------------
 #define SPEC_CHUNK 8
 __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int k, int S,

@@ -20,6 +20,8 @@ MU_SPECIE = np.array([2.0158, 4.0026, 1.0079, 1.0074, 4.0021, 4.0016, 0.0005, 14
 GAMMA_SPECIE = np.array([7. / 5, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 5. / 3, 15.6354113, 4.913,
                          1.0125, 2.364, 3.02, 10., 10., 10.])
 F_GAS = np.array([.86, .14] + [0.] * 13)
+F_DUST = np.array([0.] * 7 + [0.125] * 8)        # drv:84,114 (dust_base, normalised)
+DUST_MASS = 0.05000000001 / 715. * SOLAR         # drv:76
 
 
 def _finish(pts, vel, mass, T, ptype=None, f_un=None, light=False):
@@ -126,5 +128,19 @@ def cfl_dt(state, k=40, courant=0.25):
     return float(courant * hbar / (vmax + cs))
 
 
-WORKLOADS = {"uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
+def dusty_sphere(n, seed=12350, dust_frac=0.05, **kw):
+    """C1 with a fraction of the particles turned into dust SPH particles (particle_type 2,
+    drv:127,150-152): exercises dust density and the gas-dust drag (nsc:719-742)."""
+    s = uniform_sphere(n, seed=seed, **kw)
+    rs = np.random.RandomState(seed + 1)
+    dust = rs.permutation(n)[:int(round(dust_frac * n))]
+    ptype = np.zeros(n)
+    ptype[dust] = 2.
+    mass = s["mass"].copy()
+    mass[dust] = DUST_MASS
+    f_un = np.where((ptype == 2.)[:, None], F_DUST[None, :], F_GAS[None, :])
+    return _finish(s["points"], s["velocities"], mass, s["T"], ptype=ptype, f_un=f_un)
+
+
+WORKLOADS = {"dusty_sphere": dusty_sphere, "uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
              "uniform_cube": uniform_cube}

@@ -15,7 +15,7 @@ from ._lib import dp, f64
 
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
-                 incremental=False):
+                 incremental=False, with_drag=False):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -34,6 +34,13 @@ class Simulation:
             dp(f64(state["particle_type"], (n,))), dp(fu), dp(f64(state["T"], (n,))),
             dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
             dp(f64(state["E_internal"], (n,))), dp(acc)))
+        if with_drag:
+            # per-particle mean grain mass / cross-section as nsc.net_impulse forms them (nsc:720-726)
+            from . import compat
+            fu_all = f64(state["f_un"])
+            mgm = np.ascontiguousarray(np.sum(compat.grain_mass() * fu_all, axis=1))
+            mcs = np.ascontiguousarray(np.sum(compat.sigma_effective() * fu_all, axis=1))
+            c.check(c.lib.sphx_state_set_drag(c.h, dp(mgm), dp(mcs)))
 
     def step(self, nsteps=1, fixed_dt=0.0):
         c = self.ctx

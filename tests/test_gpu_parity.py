@@ -257,6 +257,39 @@ def test_step_trajectory_vs_oracle(workload):
     np.testing.assert_allclose(got["T"], ref["T"], rtol=1e-9)
 
 
+def test_step_with_drag_vs_oracle():
+    """Gas-dust drag inside the fused step (sphx_state_set_drag; nsc:719-742, drv:455-473) on a
+    5 %-dust sphere vs the oracle's step(with_drag=True).  The reaction is a scatter-add with
+    float atomics, so agreement is to rounding (rtol 1e-9), not bitwise."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K, nsteps = 4096, 40, 6
+    s0 = ics.dusty_sphere(n)
+    assert (s0["particle_type"] == 2).sum() > 100
+    sim = Simulation(s0, n_neigh=K, with_drag=True)
+    plain = Simulation(s0, n_neigh=K)
+    ref = dict(s0)
+    for it in range(nsteps):
+        sim.step(1)
+        plain.step(1)
+        ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0), with_drag=True)
+    got = sim.download()
+    L = np.max(np.abs(ref["points"]))
+    V = np.max(np.abs(ref["velocities"]))
+    A = np.max(np.abs(ref["total_accel"]))
+    assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * L
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * V
+    assert np.max(np.abs(got["total_accel"] - ref["total_accel"])) <= 1e-9 * A
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
+    # the drag term is really there: dust particles feel only the reaction (+ gravity = 0 here)
+    dust = s0["particle_type"] == 2
+    assert np.max(np.abs(got["total_accel"][dust])) > 0.0
+    np.testing.assert_allclose(got["total_accel"][dust], ref["total_accel"][dust], rtol=1e-7,
+                               atol=1e-9 * np.max(np.abs(ref["total_accel"][dust])))
+    assert np.max(np.abs(plain.download()["total_accel"][dust])) == 0.0
+
+
 def test_incremental_search_is_exact():
     """Verlet-list refresh (sphx_refresh.hip): with a small fixed dt most steps take the kNN from
     the candidate lists; the trajectory must be bit-identical to the full search every step."""
