@@ -70,7 +70,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("SPHX_FORCE_DIST") == "1":     # the latter: 1-rank rehearsal of the RCCL path
         from sph_code_amd import multigpu
         return multigpu.bench_main(args, rank, local_rank, world)
 
