@@ -66,6 +66,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_CELL")) { double v = atof(e); if (v > 0.0) ctx->cell_factor = v; }
     if (const char* e = getenv("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
     if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
@@ -98,7 +101,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
+                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -175,6 +178,7 @@ extern "C" int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* poi
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
     HIPCHK(hipSetDevice(ctx->device));
     ctx->map_perm = nullptr;
+    ctx->qorder = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
     SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->in_b, nb));
@@ -227,6 +231,7 @@ extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const i
         return sphx_set_err(ctx, SPHX_E_ARG, "species output needs f_un and 1 <= s <= %d", SPHX_MAX_SPECIES);
     HIPCHK(hipSetDevice(ctx->device));
     ctx->map_perm = nullptr;
+    ctx->qorder = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
     SPHX_TRY(upload(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
     SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
@@ -338,6 +343,8 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     const int64_t n = ctx->n;
     hipEvent_t* ev = ctx->ev;
     ctx->map_perm = nullptr;
+    ctx->qorder = nullptr;
+    ctx->blob_lists = false;
     HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238
     SPHX_TRY(sphx_clamp(ctx, n, ctx->st));
@@ -376,6 +383,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             SPHX_TRY(sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint));
         }
         SPHX_TRY(sphx_permute_state(ctx, n));
+        if (ctx->use_blob && !ctx->use_verlet) SPHX_TRY(sphx_build_blob_order(ctx, n));
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         StateArrays& r = ctx->st;
         KnnOut o;
@@ -403,6 +411,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     StateArrays& s = ctx->st;
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
+    if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
                        s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
                        s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),

@@ -1,0 +1,480 @@
+// sphx_blob.hip - the sum passes of the step loop with the neighbour records staged in LDS.
+//
+// In blob order (sphx_grid.hip: sphx_build_blob_order) the BLOB_P particles of a workgroup form a
+// compact blob and share most of their neighbours: 128 particles x 40 references name only ~600
+// distinct particles.  blob_dedup_kernel finds that distinct set once per step with an open-
+// addressing hash table in LDS whose entry number IS the slot number: it rewrites the workgroup's
+// part of the neighbour list as 16-bit slot numbers and stores the table (slot -> particle, -1 =
+// empty).  Each pass then fetches every distinct record ONCE per workgroup into an LDS image
+// (~5 gathers per particle instead of 40) and runs its neighbour loop out of LDS.
+//
+// Two lanes serve one particle: lane 2t takes the even list positions, lane 2t+1 the odd ones, and
+// each pair of terms is added in list order (own term, then the partner's, fetched by DPP), so
+// arithmetic and summation order are exactly those of the gather kernels in sphx_sums.hip and the
+// results are bit-identical to them.  256 threads per workgroup, two workgroups per CU (LDS-bound):
+// two waves per SIMD hide LDS latency, and one workgroup stages while the other computes.
+//
+// LDS image: BLOB_S slots; a record is kept as 16-byte chunks, chunk c of slot s at
+// (c * BLOB_S + s) * 16, so one ds_read_b128 of 16 lanes meets 16 bank-quads selected by s mod 16.
+// The workgroup's slot lists (K x BLOB_P x 2 B) sit next to it: the neighbour loop touches only LDS.
+// A reference that found no free entry within BLOB_PROBES probes (blobs with more than ~900
+// distinct neighbours; the most seen at BLOB_P = 128 is ~800) keeps the 0xFFFE marker and is
+// fetched from global memory through the int32 list.
+#include "sphx_internal.h"
+#pragma clang fp contract(off)
+#include <float.h>
+
+#define BLOB_P 128                  // particles per workgroup
+#define BLOB_T 256                  // threads per workgroup (two lanes per particle)
+#define BLOB_S 960                  // hash-table entries = image slots
+#define BLOB_PROBES 96
+#define SLOT_NONE 0xFFFFu           // no neighbour (list shorter than K)
+#define SLOT_OVER 0xFFFEu           // neighbour not staged: read it from global memory
+#define DD_BATCH 4                  // list entries fetched together per lane by the dedup kernel
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned slot_hash(int j) {
+    return (unsigned)(((u64)((unsigned)j * 2654435761u) * (u64)BLOB_S) >> 32);
+}
+
+// ---- once per step: distinct neighbours of each workgroup ------------------------------------
+__global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int k, int slots,
+                                                            const int* __restrict__ nbr, u16* slot16,
+                                                            int* uniq) {
+    __shared__ int tab[BLOB_S];
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int p = b * BLOB_P + t;
+    for (int q = threadIdx.x; q < BLOB_S; q += BLOB_T) tab[q] = (q < slots) ? -1 : -2;    // -2: closed
+    __syncthreads();
+    if (p < npad) {
+        const int nm = (k + 1) >> 1;
+        for (int m0 = 0; m0 < nm; m0 += DD_BATCH) {
+            int jb[DD_BATCH];
+#pragma unroll
+            for (int u = 0; u < DD_BATCH; ++u) {
+                const int kk = 2 * (m0 + u) + half;
+                jb[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < DD_BATCH; ++u) {
+                const int kk = 2 * (m0 + u) + half;
+                if (kk >= k) continue;
+                const int j = jb[u];
+                unsigned s = SLOT_NONE;
+                if (j >= 0) {
+                    unsigned h = slot_hash(j);
+                    s = SLOT_OVER;
+                    for (int probe = 0; probe < BLOB_PROBES; ++probe) {
+                        int e = tab[h];
+                        if (e == -1) {
+                            e = atomicCAS(&tab[h], -1, j);
+                            if (e == -1) e = j;
+                        }
+                        if (e == j) { s = h; break; }
+                        h = (h + 1 == BLOB_S) ? 0u : h + 1;
+                    }
+                }
+                slot16[(size_t)kk * npad + p] = (u16)s;
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < BLOB_S; q += BLOB_T) uniq[(size_t)b * BLOB_S + q] = tab[q];
+}
+
+int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    SPHX_TRY(sphx_ensure(ctx, ctx->slot16, (size_t)k * npad * sizeof(u16) + 512));   // tiles are read in whole rows
+    SPHX_TRY(sphx_ensure(ctx, ctx->uniq, (size_t)nblk * BLOB_S * sizeof(int)));
+    int slots = ctx->blob_slots;
+    if (slots < 1) slots = 1;
+    if (slots > BLOB_S) slots = BLOB_S;
+    hipLaunchKernelGGL(blob_dedup_kernel, dim3(nblk), dim3(BLOB_T), 0, ctx->stream, (int)n, (int)npad, k, slots,
+                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>());
+    HIPCHK(hipGetLastError());
+    ctx->blob_lists = true;
+    return SPHX_OK;
+}
+
+// ---- helpers -----------------------------------------------------------------------------------
+struct Q4 { double a, b, c, d; };
+__device__ __forceinline__ Q4 gload4(const double* p) {
+    const double2 lo = *reinterpret_cast<const double2*>(p);
+    const double2 hi = *reinterpret_cast<const double2*>(p + 2);
+    return Q4{lo.x, lo.y, hi.x, hi.y};
+}
+// chunks 2c, 2c+1 of slot s
+__device__ __forceinline__ Q4 lload4(const double2* img, int s, int c2) {
+    const double2 lo = img[(2 * c2) * BLOB_S + s];
+    const double2 hi = img[(2 * c2 + 1) * BLOB_S + s];
+    return Q4{lo.x, lo.y, hi.x, hi.y};
+}
+// the value held by the other lane of the pair (lane ^ 1), moved inside the VALU
+__device__ __forceinline__ double pair_swap(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// acc += own term, then the partner's: list order for the even lane of the pair (the odd lane's
+// copy is never stored)
+__device__ __forceinline__ void pair_add(double& acc, double term) {
+    acc += term;
+    acc += pair_swap(term);
+}
+
+#define NSTAGE ((BLOB_S + BLOB_T - 1) / BLOB_T)
+#define NB 4        // neighbours in flight per lane
+#define IMG_BYTES(per_slot, k) ((size_t)BLOB_S * (per_slot) + (size_t)(k) * BLOB_P * sizeof(u16))
+
+// Fill the workgroup's LDS: slot lists (16-B pieces) and the records of the occupied table entries.
+// NSIDE 1: one 8-B side value per slot.  NSIDE 2 (pass 3): g0 replaces the record's last double
+// (cs, unused there) and g1 is the side value.  All global loads are issued before the first use.
+template <int NSIDE, class Rec>
+__device__ __forceinline__ void stage(double2* img, double* side, u16* tile, const Rec* __restrict__ rec,
+                                      const double* __restrict__ g0, int g0_stride,
+                                      const double* __restrict__ g1, int g1_stride,
+                                      const int* __restrict__ uq, const u16* __restrict__ slot16, int npad,
+                                      int k, int b) {
+    int ju[NSTAGE];
+#pragma unroll
+    for (int r = 0; r < NSTAGE; ++r) {
+        const int s = threadIdx.x + r * BLOB_T;
+        ju[r] = (s < BLOB_S) ? uq[s] : -1;
+    }
+    const int pieces = k * (BLOB_P / 8);
+    for (int q = threadIdx.x; q < pieces; q += BLOB_T) {
+        const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
+        *reinterpret_cast<uint4*>(tile + kk * BLOB_P + c * 8) = v;
+    }
+    double2 c[NSTAGE][4];
+    double e0[NSTAGE], e1[NSTAGE];
+#pragma unroll
+    for (int r = 0; r < NSTAGE; ++r) {
+        const int j = ju[r] < 0 ? 0 : ju[r];
+        const double2* g = reinterpret_cast<const double2*>(&rec[j]);       // empty entry: particle 0, not stored
+        c[r][0] = g[0]; c[r][1] = g[1]; c[r][2] = g[2]; c[r][3] = g[3];
+        e0[r] = (NSIDE > 0) ? g0[(size_t)j * g0_stride] : 0.0;
+        e1[r] = (NSIDE > 1) ? g1[(size_t)j * g1_stride] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < NSTAGE; ++r) {
+        const int s = threadIdx.x + r * BLOB_T;
+        if (ju[r] >= 0) {
+            if (NSIDE == 2) c[r][3].y = e0[r];
+            img[0 * BLOB_S + s] = c[r][0]; img[1 * BLOB_S + s] = c[r][1];
+            img[2 * BLOB_S + s] = c[r][2]; img[3 * BLOB_S + s] = c[r][3];
+            if (NSIDE == 1) side[s] = e0[r];
+            if (NSIDE == 2) side[s] = e1[r];
+        }
+    }
+}
+
+// ---- pass 1: rho, rho_dust, n, grad P        nsc:588-619 --------------------------------------
+__global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                              const u16* __restrict__ slot16,
+                                                              const int* __restrict__ uniq,
+                                                              const int* __restrict__ qorder,
+                                                              const RecA* __restrict__ rec, double* rho_s,
+                                                              double* rho, double* rhod, double* nden, double* G,
+                                                              double* ha) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
+    u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int p = b * BLOB_P + t;
+    const int i = (p < n) ? qorder[p] : 0;
+    stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+    const double* self = reinterpret_cast<const double*>(&rec[i]);
+    const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
+    __syncthreads();
+    if (p >= n) return;
+    double xr = s0.a, yr = s0.b, zr = s0.c;
+    {
+        const unsigned sl0 = tile[t];
+        if (sl0 < SLOT_OVER) { const Q4 r = lload4(img, (int)sl0, 0); xr = r.a; yr = r.b; zr = r.c; }
+        else if (sl0 == SLOT_OVER) { const int j0 = nbr[p]; xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
+    }
+    const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
+    double s_rho = 0.0, s_rd = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    const int nm = (k + 1) >> 1;
+    for (int m0 = 0; m0 < nm; m0 += NB) {
+        unsigned sl[NB];
+        Q4 q0b[NB], q1b[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int kk = 2 * (m0 + u) + half;
+            sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (sl[u] < SLOT_OVER) { q0b[u] = lload4(img, (int)sl[u], 0); q1b[u] = lload4(img, (int)sl[u], 1); }
+            else if (sl[u] == SLOT_OVER) {
+                const double* q = reinterpret_cast<const double*>(&rec[nbr[(size_t)(2 * (m0 + u) + half) * npad + p]]);
+                q0b[u] = gload4(q); q1b[u] = gload4(q + 4);
+            } else { q0b[u] = s0; q1b[u] = s1; }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const bool ok = sl[u] != SLOT_NONE;
+            const Q4 q0 = q0b[u], q1 = q1b[u];
+            const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
+            const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
+            const double r2 = r * r;                              // nsc:588 squares the rounded distance
+            const double qj = q0.d - r2;
+            const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
+            double W = c1 * (qj * qj * qj);                       // nsc:588
+            W = (W < 0.0) ? 0.0 : W;                              // nsc:589
+            const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
+            const double qi = hi2 - r2;
+            const double ca = ci * (qi * qi);                     // nsc:592
+            pair_add(s_rho, ok ? fmax(ms, 0.0) * W : 0.0);        // nsc:605
+            pair_add(s_rd, ok ? fmax(-ms, 0.0) * W : 0.0);        // nsc:606
+            pair_add(s_n, ok ? Nw * W : 0.0);                     // nsc:607
+            pair_add(gx, ok ? (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5 : 0.0);   // nsc:615
+            pair_add(gy, ok ? (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5 : 0.0);
+            pair_add(gz, ok ? (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5 : 0.0);
+        }
+    }
+    if (half) return;
+    rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+    rho_s[i] = s_rho;
+    G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
+    ha[3 * (size_t)i + 0] = -gx / s_rho;                          // nsc:619
+    ha[3 * (size_t)i + 1] = -gy / s_rho;
+    ha[3 * (size_t)i + 2] = -gz / s_rho;
+}
+
+// ---- pass 2: Pi_i, crossing time             nsc:639-649, nsc:776-786 --------------------------
+__global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                         const u16* __restrict__ slot16,
+                                                         const int* __restrict__ uniq,
+                                                         const int* __restrict__ qorder,
+                                                         const RecB* __restrict__ recb,
+                                                         const double* __restrict__ rho_s,
+                                                         const RecSelf* __restrict__ selfr, RecBC* bc, double* Pi,
+                                                         u64* ct_bits) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, BLOB_S doubles, slot tile
+    __shared__ u64 sm[BLOB_T / 64];
+    double* lrho = reinterpret_cast<double*>(img + 4 * BLOB_S);
+    u16* tile = reinterpret_cast<u16*>(lrho + BLOB_S);
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int p = b * BLOB_P + t;
+    const int i = (p < n) ? qorder[p] : 0;
+    stage<1>(img, lrho, tile, recb, rho_s, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+    const RecSelf sf = selfr[i];
+    const double rho_i = rho_s[i];
+    const double* selfq = reinterpret_cast<const double*>(&recb[i]);
+    const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
+    __syncthreads();
+    u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
+    if (p < n) {
+        Q4 r0 = self0, rv = selfv;
+        {
+            const unsigned sl0 = tile[t];
+            if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
+            else if (sl0 == SLOT_OVER) {
+                const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
+                r0 = gload4(rq); rv = gload4(rq + 4);
+            }
+        }
+        const double cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
+        double s_pi = 0.0, maxrel = 0.0;
+        const int nm = (k + 1) >> 1;
+        for (int m0 = 0; m0 < nm; m0 += NB) {
+            unsigned sl[NB];
+            Q4 q0b[NB], qvb[NB];
+            double rhob[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int kk = 2 * (m0 + u) + half;
+                sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (sl[u] < SLOT_OVER) {
+                    q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);
+                    rhob[u] = lrho[sl[u]];
+                } else if (sl[u] == SLOT_OVER) {
+                    const int jj = nbr[(size_t)(2 * (m0 + u) + half) * npad + p];
+                    const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+                    q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
+                    rhob[u] = rho_s[jj];
+                } else { q0b[u] = self0; qvb[u] = selfv; rhob[u] = rho_i; }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const bool ok = sl[u] != SLOT_NONE;
+                const Q4 q0 = q0b[u], qv = qvb[u];
+                const double rho_j = rhob[u];
+                const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+                const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const double dot = dvx * dx + dvy * dy + dvz * dz;
+                double w = dot / sqrt(r2 + 0.01 * q0.d);                        // nsc:643
+                w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
+                const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
+                const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
+                pair_add(s_pi, ok ? -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab : 0.0);   // nsc:649
+                if (ok) maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);        // nsc:780
+            }
+        }
+        maxrel = fmax(maxrel, pair_swap(maxrel));
+        if (!half) {
+            Pi[i] = s_pi;
+            bc[i].Bw = fmax(ms_i, 0.0) * s_pi;                                  // m Pi [t==0]  nsc:651
+            if (ms_i > 0.0) {                                                   // gas only     nsc:782
+                double ct = h_i / sqrt(maxrel);
+                if (ct != ct) ct = 0.0;                                         // nan_to_num
+                if (ct > DBL_MAX) ct = DBL_MAX;
+                if (ct > 0.0) my_ct = (u64)__double_as_longlong(ct);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 q = __shfl_xor(my_ct, o, 64);
+        my_ct = q < my_ct ? q : my_ct;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = my_ct;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 r = sm[0];
+        for (int w = 1; w < BLOB_T / 64; ++w) r = sm[w] < r ? sm[w] : r;
+        if (r != 0x7FF0000000000000ull) atomicMin(ct_bits, r);
+    }
+}
+
+// ---- pass 3: viscous acceleration + heat      nsc:651-654 --------------------------------------
+__global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                           const u16* __restrict__ slot16,
+                                                           const int* __restrict__ uniq,
+                                                           const int* __restrict__ qorder,
+                                                           const RecB* __restrict__ recb,
+                                                           const RecBC* __restrict__ bc,
+                                                           const double* __restrict__ m, double* va, double* vh) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks {x y | z h2 | vx vy | vz Bw}, c1, tile
+    double* lc1 = reinterpret_cast<double*>(img + 4 * BLOB_S);
+    u16* tile = reinterpret_cast<u16*>(lc1 + BLOB_S);
+    const int b = xcd_block(blockIdx.x, gridDim.x);
+    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int p = b * BLOB_P + t;
+    const int i = (p < n) ? qorder[p] : 0;
+    const double* bcd = reinterpret_cast<const double*>(bc);
+    stage<2>(img, lc1, tile, recb, bcd, 2, bcd + 1, 2, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+    const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
+    const double* selfq = reinterpret_cast<const double*>(&recb[i]);
+    const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
+    const double mi = m[i];
+    __syncthreads();
+    if (p >= n) return;
+    Q4 r0 = self0, rv = selfv;
+    {
+        const unsigned sl0 = tile[t];
+        if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
+        else if (sl0 == SLOT_OVER) {
+            const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
+            r0 = gload4(rq); rv = gload4(rq + 4);
+        }
+    }
+    const double hi2 = self0.d, ci = -6.0 * bci.y, Bi = bci.x;
+    double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
+    const int nm = (k + 1) >> 1;
+    for (int m0 = 0; m0 < nm; m0 += NB) {
+        unsigned sl[NB];
+        Q4 q0b[NB], qvb[NB];
+        double c1b[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int kk = 2 * (m0 + u) + half;
+            sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (sl[u] < SLOT_OVER) {
+                q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);     // qv.d = Bw_j
+                c1b[u] = lc1[sl[u]];
+            } else if (sl[u] == SLOT_OVER) {
+                const int jj = nbr[(size_t)(2 * (m0 + u) + half) * npad + p];
+                const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+                q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
+                const double2 tt = *reinterpret_cast<const double2*>(&bc[jj]);
+                qvb[u].d = tt.x; c1b[u] = tt.y;
+            } else { q0b[u] = self0; qvb[u] = selfv; c1b[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const bool ok = sl[u] != SLOT_NONE;
+            const Q4 q0 = q0b[u], qv = qvb[u];
+            const double c1 = c1b[u], Bj = qv.d;
+            const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+            const double r = sqrt(dx * dx + dy * dy + dz * dz);
+            const double r2 = r * r;
+            const double qj = q0.d - r2, qi = hi2 - r2;
+            const double cb = -6.0 * c1 * (qj * qj);
+            const double ca = ci * (qi * qi);
+            const double bx = ok ? (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0 : 0.0;          // nsc:651
+            const double by = ok ? (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0 : 0.0;
+            const double bz = ok ? (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0 : 0.0;
+            pair_add(ax, bx); pair_add(ay, by); pair_add(az, bz);
+            pair_add(heat, ok ? bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c) : 0.0);   // nsc:653
+        }
+    }
+    if (half) return;
+    va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
+    vh[i] = heat * mi / 2.0;                                                    // nsc:654
+}
+
+// ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
+static int blob_attr_once(sphx_ctx* ctx) {
+    if (ctx->blob_attr_set) return SPHX_OK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_pi_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_visc_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+    ctx->blob_attr_set = true;
+    return SPHX_OK;
+}
+
+int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
+    SPHX_TRY(blob_attr_once(ctx));
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    hipLaunchKernelGGL(blob_density_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k,
+                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
+                       ctx->qorder, ctx->rec1.as<RecA>(), ctx->rho_s.as<double>(), ctx->rho.as<double>(),
+                       ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>());
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
+    SPHX_TRY(blob_attr_once(ctx));
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    hipLaunchKernelGGL(blob_pi_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k,
+                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
+                       ctx->qorder, ctx->recv.as<RecB>(), ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(),
+                       ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(), ct_bits);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
+    SPHX_TRY(blob_attr_once(ctx));
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    hipLaunchKernelGGL(blob_visc_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k,
+                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
+                       ctx->qorder, ctx->recv.as<RecB>(), ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),
+                       ctx->vh.as<double>());
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

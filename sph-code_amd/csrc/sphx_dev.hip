@@ -62,6 +62,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     const int64_t n = n_total;
     const size_t nb = (size_t)n * sizeof(double);
     ctx->map_perm = nullptr;
+    ctx->qorder = nullptr;
     DevBuf* bufs[] = {&ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g};
     for (DevBuf* b : bufs) SPHX_TRY(sphx_ensure(ctx, *b, nb));
     double *x = ctx->in_b.as<double>(), *y = ctx->in_c.as<double>(), *z = ctx->in_d.as<double>();
@@ -76,6 +77,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     HIPCHK(hipGetLastError());
     SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * sphx_pad64(n) * sizeof(int)));
     ctx->map_perm = ctx->perm.as<int>();
+    ctx->qorder = nullptr;
     ctx->map_nactive = (int)n_owned;
     ctx->n = n;
     ctx->npad = sphx_pad64(n);

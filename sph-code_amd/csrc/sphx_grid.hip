@@ -316,3 +316,69 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
+
+// ---- blob order: particles listed cell by cell along a Morton curve ---------------------------
+// Bits of (cx, cy, cz) interleaved from the least significant end, each axis contributing only the
+// bits it has, so the code space is at most 8x the cell count whatever the grid's aspect ratio.
+struct BlobBits { int bx, by, bz; };
+__device__ __forceinline__ unsigned blob_rank(int cx, int cy, int cz, BlobBits b) {
+    unsigned out = 0;
+    int pos = 0;
+    for (int q = 0; q < 11; ++q) {
+        if (q < b.bx) out |= (unsigned)((cx >> q) & 1) << pos++;
+        if (q < b.by) out |= (unsigned)((cy >> q) & 1) << pos++;
+        if (q < b.bz) out |= (unsigned)((cz >> q) & 1) << pos++;
+    }
+    return out;
+}
+__global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.ncells) return;
+    const int cnt = cell_start[c + 1] - cell_start[c];
+    if (cnt == 0) return;
+    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    mcount[blob_rank(cx, cy, cz, b)] = cnt;
+}
+__global__ __launch_bounds__(256) void blob_scatter(int n, GridParams g, BlobBits b, const int* cell_of,
+                                                    const int* perm, const int* cell_start, const int* mstart,
+                                                    int* porder) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;       // storage (cell-sorted) index
+    if (t >= n) return;
+    const int c = cell_of[perm[t]];
+    const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+    porder[mstart[blob_rank(cx, cy, cz, b)] + (t - cell_start[c])] = t;
+}
+
+// porder[p] = storage index of the p-th particle in blob order; ctx->qorder points at it on success
+// (left nullptr = identity when the code space would be unreasonably large).
+int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
+    const GridParams g = ctx->grid;
+    BlobBits b{0, 0, 0};
+    while ((1 << b.bx) < g.nx) ++b.bx;
+    while ((1 << b.by) < g.ny) ++b.by;
+    while ((1 << b.bz) < g.nz) ++b.bz;
+    const int bits = b.bx + b.by + b.bz;
+    ctx->qorder = nullptr;
+    if (bits > 27) return SPHX_OK;
+    const int M = 1 << bits;
+    SPHX_TRY(sphx_ensure(ctx, ctx->porder, (size_t)n * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->mcount, ((size_t)M + 2) * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->mstart, ((size_t)M + 2) * sizeof(int)));
+    const int nblk = (M + SCAN_TILE - 1) / SCAN_TILE;
+    SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, ((size_t)nblk + 2) * sizeof(int)));
+    int* mc = ctx->mcount.as<int>();
+    int* ms = ctx->mstart.as<int>();
+    int* bsum = ctx->scan_tmp.as<int>();
+    HIPCHK(hipMemsetAsync(mc, 0, ((size_t)M + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(blob_count, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, ctx->stream, g, b,
+                       ctx->cell_start.as<int>(), mc);
+    hipLaunchKernelGGL(scan_phase1, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, M, mc, bsum);
+    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, nblk, bsum, bsum + nblk);
+    hipLaunchKernelGGL(scan_phase3, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, M, mc, bsum, ms);
+    hipLaunchKernelGGL(blob_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, b,
+                       ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->cell_start.as<int>(), ms,
+                       ctx->porder.as<int>());
+    HIPCHK(hipGetLastError());
+    ctx->qorder = ctx->porder.as<int>();
+    return SPHX_OK;
+}

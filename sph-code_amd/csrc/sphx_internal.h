@@ -94,6 +94,19 @@ struct sphx_ctx {
     double rscale_build = 1.3;          // search radius factor on list-building steps
     DevBuf nbr;                   // int32 [k][npad], K-major, -1 = missing
     const int* map_perm = nullptr;  // device API: sorted -> caller index (nullptr: identity)
+    // Processing order of the step loop: column p of the neighbour list / thread p of a pass works
+    // on the particle stored at qorder[p].  Storage stays x-fastest by cell (the search walks rows);
+    // the processing order follows the cells along a Morton curve, so a workgroup's particles form
+    // a compact blob and share most of their neighbours (sphx_grid.hip: sphx_build_blob_order).
+    const int* qorder = nullptr;    // nullptr: identity
+    DevBuf porder, mcount, mstart;
+    bool use_blob = true;
+    // sphx_blob.hip: per-workgroup distinct-neighbour lists + 16-bit slot lists for the LDS passes
+    DevBuf slot16, uniq;
+    bool use_lds = true;            // run the step loop's passes out of LDS (needs blob order)
+    bool blob_lists = false;        // slot lists valid for the current neighbour list
+    bool blob_attr_set = false;
+    int blob_slots = 1 << 20;       // distinct neighbours staged per workgroup (clamped to the image size)
     int map_nactive = 0;            // device API: callers' particles below this are computed
     DevBuf rho, rhod, nden, G, Pi, Bw, va, vh, ha, F;
     DevBuf scal;                  // small device scalars: ct bits, dt, counters
@@ -160,6 +173,11 @@ enum {
 // grid
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
               double out_minmax[13], bool use_clip);
+int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
+int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
+int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);
+int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits);
+int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
 // knn

@@ -28,6 +28,7 @@ struct KnnArgs {
     const double *x, *y, *z;
     const int* id;
     const int* inv;
+    const int* qorder;         // processing order: query slot p works on stored particle qorder[p] (nullable)
     const int* cell_start;
     const double* tbox;        // true bounding box {min xyz, max xyz}
     GridParams g;
@@ -139,21 +140,22 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     // particle l) and broadcast through SGPRs as each comes up
     double qx = 0.0, qy = 0.0, qz = 0.0, qr = 0.0;
     int qid = 0x7FFFFFFF;
+    int qs = 0;                      // where the lane's query particle is stored
     {
         const int ip = base + wave * (KNN_PPB / 4) + (lane & 15);
         if (lane < KNN_PPB / 4 && ip < a.n) {
-            qx = a.x[ip]; qy = a.y[ip]; qz = a.z[ip];
-            qid = a.id[ip];
-            qr = a.rsearch ? a.rsearch[a.hint_by_id ? qid : ip] * a.rscale : 0.0;
+            qs = a.qorder ? a.qorder[ip] : ip;
+            qx = a.x[qs]; qy = a.y[qs]; qz = a.z[qs];
+            qid = a.id[qs];
+            qr = a.rsearch ? a.rsearch[a.hint_by_id ? qid : qs] * a.rscale : 0.0;
         }
     }
 
     for (int t16 = 0; t16 < KNN_PPB / 4; ++t16) {
         const int li = wave * (KNN_PPB / 4) + t16;
-        const int i = base + li;
         const int oid = __builtin_amdgcn_readlane(qid, t16);
         // wave-uniform: past the end, or a ghost (a candidate, never a query)
-        if (i >= a.n || oid >= a.n_active) {
+        if (base + li >= a.n || oid >= a.n_active) {
             if (lane < K) tile(lane, li) = -1;
             continue;
         }
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             if (!LEAN && a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
             if (!LEAN && a.dist) a.dist[(long long)oid * K + lane] = d;
         }
+        const int i = __builtin_amdgcn_readlane(qs, t16);        // storage index of this query
         if (!LEAN && a.list64) {
             // Verlet list for sphx_refresh.hip: the 64 nearest inside the final radius R.  Anything
             // not listed was farther than the 64th entry (list full) or than R (list not full).
@@ -420,6 +423,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.n_active = ctx->map_perm ? ctx->map_nactive : 0x7FFFFFFF;
     a.x = xs; a.y = ys; a.z = zs;
     a.id = id; a.inv = inv;
+    a.qorder = ctx->qorder;
     a.cell_start = ctx->cell_start.as<int>();
     a.g = ctx->grid;
     a.tbox = ctx->tbox;

@@ -208,6 +208,7 @@ static int loop_begin(sphx_ctx* ctx, int64_t n, int k, const int64_t* neighbor, 
     if (k < 1 || k > 4096) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d out of range", k);
     HIPCHK(hipSetDevice(ctx->device));
     ctx->map_perm = nullptr;
+    ctx->qorder = nullptr;
     SPHX_TRY(up(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
     SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
     memset(a, 0, sizeof(*a));

@@ -127,16 +127,17 @@ __device__ __forceinline__ Q4 load4(const double* p) {
 template <int EXP>
 __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                            const RecA* __restrict__ rec, double* rho_s,
-                                                           OutMap om, double* rho,
+                                                           const int* __restrict__ qorder, OutMap om, double* rho,
                                                            double* rhod, double* nden, double* G,
                                                            double* ha) {
-    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;    // list column
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;                                         // stored particle
     const int o = out_index(om, i);
     if (o >= om.n_active) return;
     const double* self = reinterpret_cast<const double*>(&rec[i]);
     const Q4 s0 = load4(self), s1 = load4(self + 4);          // x y z h2 | c1 ms A Nw
-    int j0 = nbr[i];
+    int j0 = nbr[p];
     double xr = s0.a, yr = s0.b, zr = s0.c;
     if (j0 >= 0 && j0 != i) { xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
     const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
       int jb[NBATCH];
       Q4 q0b[NBATCH], q1b[NBATCH];
 #pragma unroll
-      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
           const double* q = reinterpret_cast<const double*>(&rec[jb[u] < 0 ? i : jb[u]]);
@@ -187,6 +188,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->nden, (size_t)n * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
+    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_density(ctx, n, k);
     if (const char* e = getenv("SPHX_PASS_EXP")) {        // timing experiment, outputs discarded
         const int mode = atoi(e);
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
@@ -197,11 +199,11 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
         if (mode == 1)
             hipLaunchKernelGGL(pass_density_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                                (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
-                               OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
+                               ctx->qorder, OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
         else
             hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                                (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
-                               OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
+                               ctx->qorder, OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
         HIPCHK(hipEventRecord(e1, ctx->stream));
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -211,7 +213,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     }
     hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
-                       ctx->rho_s.as<double>(), OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
+                       ctx->rho_s.as<double>(), ctx->qorder, OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
                        ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
@@ -237,13 +239,14 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
                                                       const RecB* __restrict__ recb,
                                                       const double* __restrict__ rho_s,
                                                       const RecSelf* __restrict__ selfr, RecBC* bc,
-                                                      OutMap om, double* Pi, double* BwOut,
+                                                      const int* __restrict__ qorder, OutMap om, double* Pi, double* BwOut,
                                                       u64* ct_bits) {
-    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
+    const int i = (p < n) ? (qorder ? qorder[p] : p) : n;
     const int o = (i < n) ? out_index(om, i) : 0x7FFFFFFF;
     if (i < n && o < om.n_active) {
-        int j0 = nbr[i];
+        int j0 = nbr[p];
         if (j0 < 0) j0 = i;
         const double* rq = reinterpret_cast<const double*>(&recb[j0]);
         const Q4 r0 = load4(rq), rv = load4(rq + 4);                         // x y z h2 | vx vy vz cs
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
           Q4 q0b[NBATCH], qvb[NBATCH];
           double rhob[NBATCH];
 #pragma unroll
-          for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+          for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
           for (int u = 0; u < NBATCH; ++u) {
               const int jj = jb[u] < 0 ? i : jb[u];
@@ -301,9 +304,10 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
     SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
+    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_pi(ctx, n, k, ct);
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
-                       ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(),
+                       ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->qorder,
                        OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->Pi.as<double>(), ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct);
     HIPCHK(hipGetLastError());
@@ -313,14 +317,16 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
 // ---- pass 3 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                         const RecB* __restrict__ recb,
-                                                        const RecBC* __restrict__ bc, OutMap om,
+                                                        const RecBC* __restrict__ bc,
+                                                        const int* __restrict__ qorder, OutMap om,
                                                         const double* __restrict__ m, double* va,
                                                         double* vh) {
-    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;
     const int o = out_index(om, i);
     if (o >= om.n_active) return;
-    int j0 = nbr[i];
+    int j0 = nbr[p];
     if (j0 < 0) j0 = i;
     const double* rq = reinterpret_cast<const double*>(&recb[j0]);
     const Q4 r0 = load4(rq), rv = load4(rq + 4);
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
       Q4 q0b[NBATCH], qvb[NBATCH];
       double2 bcb[NBATCH];
 #pragma unroll
-      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+      for (int u = 0; u < NBATCH; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
           const int jj = jb[u] < 0 ? i : jb[u];
@@ -366,9 +372,11 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->va, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
+    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_visc(ctx, n, k, m);
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
-                       ctx->bc_s.as<RecBC>(), OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
+                       ctx->bc_s.as<RecBC>(), ctx->qorder,
+                       OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
                        ctx->va.as<double>(), ctx->vh.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -383,15 +391,17 @@ __global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, 
                                                         const double* __restrict__ m,
                                                         const double* __restrict__ ptype,
                                                         const double* __restrict__ mgm,
-                                                        const double* __restrict__ mcs, double* onto,
+                                                        const double* __restrict__ mcs,
+                                                        const int* __restrict__ qorder, double* onto,
                                                         double* react) {
-    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;
     const double* rq = reinterpret_cast<const double*>(&recb[i]);
     const Q4 r0 = load4(rq), rv = load4(rq + 4);
     double ox = 0.0, oy = 0.0, oz = 0.0;
     for (int kk = 0; kk < k; ++kk) {
-        const int j = nbr[(size_t)kk * npad + i];
+        const int j = nbr[(size_t)kk * npad + p];
         if (j < 0 || ptype[j] != 2.0) continue;                  // dust neighbours only   nsc:736
         const double* qb = reinterpret_cast<const double*>(&recb[j]);
         const Q4 q0 = load4(qb), qv = load4(qb + 4);
@@ -420,7 +430,7 @@ int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const doubl
     SPHX_TRY(sphx_ensure(ctx, ctx->drag_re, (size_t)n * 3 * sizeof(double)));
     HIPCHK(hipMemsetAsync(ctx->drag_re.p, 0, (size_t)n * 3 * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(pass_drag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(), m, ptype, mgm, mcs,
+                       (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(), m, ptype, mgm, mcs, ctx->qorder,
                        ctx->drag_on.as<double>(), ctx->drag_re.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -431,11 +441,13 @@ int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const doubl
 __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int k, int S,
                                                            const int* __restrict__ nbr,
                                                            const RecA* __restrict__ rec,
-                                                           const double* __restrict__ fun, double* F) {
-    int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                           const double* __restrict__ fun,
+                                                           const int* __restrict__ qorder, double* F) {
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;
     const int s0 = blockIdx.y * SPEC_CHUNK;
-    int j0 = nbr[i];
+    int j0 = nbr[p];
     if (j0 < 0) j0 = i;
     const double xr = rec[j0].x, yr = rec[j0].y, zr = rec[j0].z;
     double acc[SPEC_CHUNK];
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
     for (int q = 0; q < SPEC_CHUNK; ++q) acc[q] = 0.0;
 #pragma unroll 4
     for (int kk = 0; kk < k; ++kk) {
-        int j = nbr[(size_t)kk * npad + i];
+        int j = nbr[(size_t)kk * npad + p];
         if (j < 0) continue;
         const double* q = reinterpret_cast<const double*>(&rec[j]);
         const Q4 q0 = load4(q);
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256) void pass_species_kernel(int n, int npad, int 
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F) {
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)((s + SPEC_CHUNK - 1) / SPEC_CHUNK));
     hipLaunchKernelGGL(pass_species_kernel, grid, dim3(256), 0, ctx->stream, (int)n,
-                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun, F);
+                       (int)sphx_pad64(n), k, s, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun, ctx->qorder, F);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -311,6 +311,30 @@ def test_incremental_search_is_exact():
     assert st["refresh_steps"] + st["rebuild_steps"] == nsteps
 
 
+@pytest.mark.parametrize("workload,n", [("polytrope", 20000), ("dusty_sphere", 6000)])
+def test_step_loop_variants_are_bit_identical(workload, n, monkeypatch):
+    """The step loop's passes exist in three forms that must agree bit for bit: gathers in storage
+    order (SPHX_BLOB=0), gathers in blob order (SPHX_LDS=0), neighbour records staged in LDS
+    (default) - the last also with the image squeezed to 300 slots, so that part of the references
+    take the global-memory fallback."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    s0 = ics.WORKLOADS[workload](n)
+    res = {}
+    for name, env in (("lds", {}), ("lds_overflow", {"SPHX_BLOB_SLOTS": "300"}), ("blob_gather", {"SPHX_LDS": "0"}),
+                      ("storage_order", {"SPHX_BLOB": "0"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        sim = Simulation(s0, n_neigh=40)          # a fresh context reads the switches
+        sim.step(4)
+        res[name] = sim.download()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for name in ("lds_overflow", "blob_gather", "storage_order"):
+        for key in ("points", "velocities", "E_internal", "T", "sizes", "densities", "total_accel"):
+            assert np.array_equal(res["lds"][key], res[name][key]), (name, key)
+
+
 def test_snapshot_restart_is_bit_identical(tmp_path):
     """A run resumed from a snapshot continues exactly like the uninterrupted one."""
     import sph_code_amd.ics as ics
