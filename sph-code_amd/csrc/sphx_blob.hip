@@ -8,10 +8,9 @@
 // empty).  Each pass then fetches every distinct record ONCE per workgroup into an LDS image
 // (~5 gathers per particle instead of 40) and runs its neighbour loop out of LDS.
 //
-// Two lanes serve one particle: lane 2t takes the even list positions, lane 2t+1 the odd ones, and
-// each pair of terms is added in list order (own term, then the partner's, fetched by DPP), so
-// arithmetic and summation order are exactly those of the gather kernels in sphx_sums.hip and the
-// results are bit-identical to them.  256 threads per workgroup, two workgroups per CU (LDS-bound):
+// Two lanes serve one particle: lane 2t sums the even list positions, lane 2t+1 the odd ones, and
+// the two partial sums are added at the end (one DPP exchange) - the same fixed order the gather
+// kernels of sphx_sums.hip use, so the results are bit-identical to theirs.  256 threads per workgroup, two workgroups per CU (LDS-bound):
 // two waves per SIMD hide LDS latency, and one workgroup stages while the other computes.
 //
 // LDS image: BLOB_S slots; a record is kept as 16-byte chunks, chunk c of slot s at
@@ -23,6 +22,8 @@
 #include "sphx_internal.h"
 #pragma clang fp contract(off)
 #include <float.h>
+#include <stdlib.h>
+#include <stdio.h>
 
 #define BLOB_P 128                  // particles per workgroup
 #define BLOB_T 256                  // threads per workgroup (two lanes per particle)
@@ -30,7 +31,7 @@
 #define BLOB_PROBES 96
 #define SLOT_NONE 0xFFFFu           // no neighbour (list shorter than K)
 #define SLOT_OVER 0xFFFEu           // neighbour not staged: read it from global memory
-#define DD_BATCH 4                  // list entries fetched together per lane by the dedup kernel
+#define DD_BATCH 8                  // list entries fetched together per lane by the dedup kernel
 
 typedef unsigned short u16;
 
@@ -50,12 +51,19 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
     __syncthreads();
     if (p < npad) {
         const int nm = (k + 1) >> 1;
+        int jn[DD_BATCH];                         // the next batch is in flight while this one is hashed
+#pragma unroll
+        for (int u = 0; u < DD_BATCH; ++u) {
+            const int kk = 2 * u + half;
+            jn[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
+        }
         for (int m0 = 0; m0 < nm; m0 += DD_BATCH) {
             int jb[DD_BATCH];
 #pragma unroll
             for (int u = 0; u < DD_BATCH; ++u) {
-                const int kk = 2 * (m0 + u) + half;
-                jb[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
+                jb[u] = jn[u];
+                const int kk = 2 * (m0 + DD_BATCH + u) + half;
+                jn[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
             }
 #pragma unroll
             for (int u = 0; u < DD_BATCH; ++u) {
@@ -119,20 +127,18 @@ __device__ __forceinline__ double pair_swap(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// acc += own term, then the partner's: list order for the even lane of the pair (the odd lane's
-// copy is never stored)
-__device__ __forceinline__ void pair_add(double& acc, double term) {
-    acc += term;
-    acc += pair_swap(term);
-}
+// even-position partial sum + odd-position partial sum (valid in both lanes of the pair)
+__device__ __forceinline__ double pair_total(double acc) { return acc + pair_swap(acc); }
 
 #define NSTAGE ((BLOB_S + BLOB_T - 1) / BLOB_T)
-#define NB 4        // neighbours in flight per lane
-#define IMG_BYTES(per_slot, k) ((size_t)BLOB_S * (per_slot) + (size_t)(k) * BLOB_P * sizeof(u16))
+#define NB 4        // neighbours in flight per lane (one batch = 2 * NB list positions)
+#define KPAD(k) ((((k) + 2 * NB - 1) / (2 * NB)) * (2 * NB))      // slot tile rows: whole batches
+#define IMG_BYTES(per_slot, k) ((size_t)BLOB_S * (per_slot) + (size_t)KPAD(k) * BLOB_P * sizeof(u16))
 
-// Fill the workgroup's LDS: slot lists (16-B pieces) and the records of the occupied table entries.
-// NSIDE 1: one 8-B side value per slot.  NSIDE 2 (pass 3): g0 replaces the record's last double
-// (cs, unused there) and g1 is the side value.  All global loads are issued before the first use.
+// Fill the workgroup's LDS: slot lists (16-B pieces; rows k..KPAD(k) read as "no neighbour") and the
+// records of the occupied table entries.  NSIDE 1: one 8-B side value per slot.  NSIDE 2 (pass 3):
+// g0 replaces the record's last double (cs, unused there) and g1 is the side value.  All global
+// loads are issued before the first use.
 template <int NSIDE, class Rec>
 __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, const Rec* __restrict__ rec,
                                       const double* __restrict__ g0, int g0_stride,
@@ -145,10 +151,11 @@ __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, con
         const int s = threadIdx.x + r * BLOB_T;
         ju[r] = (s < BLOB_S) ? uq[s] : -1;
     }
-    const int pieces = k * (BLOB_P / 8);
+    const int pieces = KPAD(k) * (BLOB_P / 8);
     for (int q = threadIdx.x; q < pieces; q += BLOB_T) {
         const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
-        const uint4 v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (kk < k) v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
         *reinterpret_cast<uint4*>(tile + kk * BLOB_P + c * 8) = v;
     }
     double2 c[NSTAGE][4];
@@ -174,8 +181,66 @@ __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, con
     }
 }
 
+// A batch of NB list positions of this lane.  FAST: every lane of the wave has a staged neighbour at
+// each of them (the usual case): straight-line LDS reads and arithmetic, nothing to branch on.
+// Otherwise a position may be empty (skipped) or unstaged (fetched through the int32 list).
+struct DensAcc { double rho, rd, n, gx, gy, gz; };
+template <bool FAST>
+__device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[NB], const double2* img,
+                                              const RecA* __restrict__ rec, const int* __restrict__ nbr,
+                                              size_t col0, size_t colstep, double xr, double yr, double zr,
+                                              double hi2, double ci, double Ai) {
+    Q4 q0b[NB], q1b[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (FAST || sl[u] < SLOT_OVER) { q0b[u] = lload4(img, (int)sl[u], 0); q1b[u] = lload4(img, (int)sl[u], 1); }
+        else if (sl[u] == SLOT_OVER) {
+            const double* q = reinterpret_cast<const double*>(&rec[nbr[col0 + u * colstep]]);
+            q0b[u] = gload4(q); q1b[u] = gload4(q + 4);
+        } else { q0b[u] = Q4{xr, yr, zr, 0.0}; q1b[u] = Q4{0.0, 0.0, 0.0, 0.0}; }
+    }
+    if (FAST) __builtin_amdgcn_sched_barrier(0);       // all of the batch's LDS reads are issued before its arithmetic
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (!FAST && sl[u] == SLOT_NONE) continue;
+        const Q4 q0 = q0b[u], q1 = q1b[u];
+        const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
+        const double r2 = r * r;                              // nsc:588 squares the rounded distance
+        const double qj = q0.d - r2;
+        const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
+        double W = c1 * (qj * qj * qj);                       // nsc:588
+        W = (W < 0.0) ? 0.0 : W;                              // nsc:589
+        const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
+        const double qi = hi2 - r2;
+        const double ca = ci * (qi * qi);                     // nsc:592
+        a.rho += fmax(ms, 0.0) * W;                           // nsc:605
+        a.rd += fmax(-ms, 0.0) * W;                           // nsc:606
+        a.n += Nw * W;                                        // nsc:607
+        a.gx += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;      // nsc:615
+        a.gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
+        a.gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
+    }
+}
+
+// the lane's slot numbers for batch m0 (tile rows beyond k hold SLOT_NONE)
+__device__ __forceinline__ void load_slots(unsigned (&sl)[NB], const u16* tile, int m0, int half, int t) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) sl[u] = tile[(2 * (m0 + u) + half) * BLOB_P + t];
+}
+__device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
+    unsigned worst = sl[0];
+#pragma unroll
+    for (int u = 1; u < NB; ++u) worst = worst > sl[u] ? worst : sl[u];
+    return __ballot(worst >= SLOT_OVER) == 0ull;
+}
+
 // ---- pass 1: rho, rho_dust, n, grad P        nsc:588-619 --------------------------------------
-__global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+// EXP != 0: timing experiments on an extra, discarded launch (SPHX_BLOB_EXP): 1 = staging only,
+// 2 = neighbour loop only (image not filled), 3 = both but no global stores at the end.
+template <int EXP>
+__global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, int k, int nblk,
+                                                              const int* __restrict__ nbr,
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
                                                               const int* __restrict__ qorder,
@@ -184,73 +249,101 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
                                                               double* ha) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
     u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
-    const int b = xcd_block(blockIdx.x, gridDim.x);
     const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const int p = b * BLOB_P + t;
-    const int i = (p < n) ? qorder[p] : 0;
-    stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
-    const double* self = reinterpret_cast<const double*>(&rec[i]);
-    const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
-    __syncthreads();
-    if (p >= n) return;
-    double xr = s0.a, yr = s0.b, zr = s0.c;
-    {
-        const unsigned sl0 = tile[t];
-        if (sl0 < SLOT_OVER) { const Q4 r = lload4(img, (int)sl0, 0); xr = r.a; yr = r.b; zr = r.c; }
-        else if (sl0 == SLOT_OVER) { const int j0 = nbr[p]; xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
+    // persistent workgroups (two per CU): blob after blob, no dispatch gap between them
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const int i = (p < n) ? qorder[p] : 0;
+        if (EXP != 2)
+            stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        else
+            for (int q = threadIdx.x; q < KPAD(k) * BLOB_P; q += BLOB_T) tile[q] = (u16)((q * 37 + b) % BLOB_S);
+        const double* self = reinterpret_cast<const double*>(&rec[i]);
+        const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
+        __syncthreads();
+        if (p < n && EXP == 1 && s0.a == 1.2345e-300) rho[i] = img[threadIdx.x].x;
+        if (p < n && EXP != 1) {
+            double xr = s0.a, yr = s0.b, zr = s0.c;
+            {
+                const unsigned sl0 = tile[t];
+                if (sl0 < SLOT_OVER) { const Q4 r = lload4(img, (int)sl0, 0); xr = r.a; yr = r.b; zr = r.c; }
+                else if (sl0 == SLOT_OVER) { const int j0 = nbr[p]; xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
+            }
+            const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
+            DensAcc a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int nm = KPAD(k) >> 1;
+            unsigned sl[NB];
+            load_slots(sl, tile, 0, half, t);
+            for (int m0 = 0; m0 < nm; m0 += NB) {
+                unsigned cur[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) cur[u] = sl[u];
+                if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);    // next batch's slots, behind this one's reads
+                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                if (all_staged(cur))
+                    density_batch<true>(a, cur, img, rec, nbr, col0, 2 * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                else
+                    density_batch<false>(a, cur, img, rec, nbr, col0, 2 * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+            }
+            const double s_rho = pair_total(a.rho), s_rd = pair_total(a.rd), s_n = pair_total(a.n);
+            const double gx = pair_total(a.gx), gy = pair_total(a.gy), gz = pair_total(a.gz);
+            if (EXP == 3) {
+                if (s_rho + gx + s_n + s_rd + gy + gz == 1.2345e-300) rho[i] = 0.0;
+            } else if (!half) {
+                rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+                rho_s[i] = s_rho;
+                G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
+                ha[3 * (size_t)i + 0] = -gx / s_rho;                  // nsc:619
+                ha[3 * (size_t)i + 1] = -gy / s_rho;
+                ha[3 * (size_t)i + 2] = -gz / s_rho;
+            }
+        }
+        __syncthreads();                                   // the image is rewritten by the next blob
     }
-    const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
-    double s_rho = 0.0, s_rd = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    const int nm = (k + 1) >> 1;
-    for (int m0 = 0; m0 < nm; m0 += NB) {
-        unsigned sl[NB];
-        Q4 q0b[NB], q1b[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int kk = 2 * (m0 + u) + half;
-            sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            if (sl[u] < SLOT_OVER) { q0b[u] = lload4(img, (int)sl[u], 0); q1b[u] = lload4(img, (int)sl[u], 1); }
-            else if (sl[u] == SLOT_OVER) {
-                const double* q = reinterpret_cast<const double*>(&rec[nbr[(size_t)(2 * (m0 + u) + half) * npad + p]]);
-                q0b[u] = gload4(q); q1b[u] = gload4(q + 4);
-            } else { q0b[u] = s0; q1b[u] = s1; }
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const bool ok = sl[u] != SLOT_NONE;
-            const Q4 q0 = q0b[u], q1 = q1b[u];
-            const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
-            const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
-            const double r2 = r * r;                              // nsc:588 squares the rounded distance
-            const double qj = q0.d - r2;
-            const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
-            double W = c1 * (qj * qj * qj);                       // nsc:588
-            W = (W < 0.0) ? 0.0 : W;                              // nsc:589
-            const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
-            const double qi = hi2 - r2;
-            const double ca = ci * (qi * qi);                     // nsc:592
-            pair_add(s_rho, ok ? fmax(ms, 0.0) * W : 0.0);        // nsc:605
-            pair_add(s_rd, ok ? fmax(-ms, 0.0) * W : 0.0);        // nsc:606
-            pair_add(s_n, ok ? Nw * W : 0.0);                     // nsc:607
-            pair_add(gx, ok ? (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5 : 0.0);   // nsc:615
-            pair_add(gy, ok ? (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5 : 0.0);
-            pair_add(gz, ok ? (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5 : 0.0);
-        }
-    }
-    if (half) return;
-    rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
-    rho_s[i] = s_rho;
-    G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
-    ha[3 * (size_t)i + 0] = -gx / s_rho;                          // nsc:619
-    ha[3 * (size_t)i + 1] = -gy / s_rho;
-    ha[3 * (size_t)i + 2] = -gz / s_rho;
 }
 
 // ---- pass 2: Pi_i, crossing time             nsc:639-649, nsc:776-786 --------------------------
-__global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+template <bool FAST>
+__device__ __forceinline__ void pi_batch(double& s_pi, double& maxrel, const unsigned (&sl)[NB], const double2* img,
+                                         const double* lrho, const RecB* __restrict__ recb,
+                                         const double* __restrict__ rho_s, const int* __restrict__ nbr, size_t col0,
+                                         size_t colstep, const Q4& r0, const Q4& rv, double rho_i, double cs_i) {
+    Q4 q0b[NB], qvb[NB];
+    double rhob[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (FAST || sl[u] < SLOT_OVER) {
+            q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);
+            rhob[u] = lrho[sl[u]];
+        } else if (sl[u] == SLOT_OVER) {
+            const int jj = nbr[col0 + u * colstep];
+            const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+            q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
+            rhob[u] = rho_s[jj];
+        } else { q0b[u] = r0; qvb[u] = rv; rhob[u] = rho_i; }
+    }
+    if (FAST) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (!FAST && sl[u] == SLOT_NONE) continue;
+        const Q4 q0 = q0b[u], qv = qvb[u];
+        const double rho_j = rhob[u];
+        const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+        const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        const double dot = dvx * dx + dvy * dy + dvz * dz;
+        double w = dot / sqrt(r2 + 0.01 * q0.d);                        // nsc:643
+        w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
+        const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
+        const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
+        s_pi += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;             // nsc:649
+        maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);       // nsc:780
+    }
+}
+
+__global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k, int nblk,
+                                                         const int* __restrict__ nbr,
                                                          const u16* __restrict__ slot16,
                                                          const int* __restrict__ uniq,
                                                          const int* __restrict__ qorder,
@@ -262,79 +355,58 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
     __shared__ u64 sm[BLOB_T / 64];
     double* lrho = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lrho + BLOB_S);
-    const int b = xcd_block(blockIdx.x, gridDim.x);
     const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const int p = b * BLOB_P + t;
-    const int i = (p < n) ? qorder[p] : 0;
-    stage<1>(img, lrho, tile, recb, rho_s, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
-    const RecSelf sf = selfr[i];
-    const double rho_i = rho_s[i];
-    const double* selfq = reinterpret_cast<const double*>(&recb[i]);
-    const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
-    __syncthreads();
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
-    if (p < n) {
-        Q4 r0 = self0, rv = selfv;
-        {
-            const unsigned sl0 = tile[t];
-            if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
-            else if (sl0 == SLOT_OVER) {
-                const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
-                r0 = gload4(rq); rv = gload4(rq + 4);
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const int i = (p < n) ? qorder[p] : 0;
+        stage<1>(img, lrho, tile, recb, rho_s, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        const RecSelf sf = selfr[i];
+        const double rho_i = rho_s[i];
+        const double* selfq = reinterpret_cast<const double*>(&recb[i]);
+        const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
+        __syncthreads();
+        if (p < n) {
+            Q4 r0 = self0, rv = selfv;
+            {
+                const unsigned sl0 = tile[t];
+                if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
+                else if (sl0 == SLOT_OVER) {
+                    const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
+                    r0 = gload4(rq); rv = gload4(rq + 4);
+                }
             }
-        }
-        const double cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
-        double s_pi = 0.0, maxrel = 0.0;
-        const int nm = (k + 1) >> 1;
-        for (int m0 = 0; m0 < nm; m0 += NB) {
+            const double cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
+            double s_pi = 0.0, maxrel = 0.0;
+            const int nm = KPAD(k) >> 1;
             unsigned sl[NB];
-            Q4 q0b[NB], qvb[NB];
-            double rhob[NB];
+            load_slots(sl, tile, 0, half, t);
+            for (int m0 = 0; m0 < nm; m0 += NB) {
+                unsigned cur[NB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int kk = 2 * (m0 + u) + half;
-                sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
+                for (int u = 0; u < NB; ++u) cur[u] = sl[u];
+                if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);
+                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                if (all_staged(cur))
+                    pi_batch<true>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, 2 * (size_t)npad, r0, rv, rho_i, cs_i);
+                else
+                    pi_batch<false>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, 2 * (size_t)npad, r0, rv, rho_i, cs_i);
             }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                if (sl[u] < SLOT_OVER) {
-                    q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);
-                    rhob[u] = lrho[sl[u]];
-                } else if (sl[u] == SLOT_OVER) {
-                    const int jj = nbr[(size_t)(2 * (m0 + u) + half) * npad + p];
-                    const double* qb = reinterpret_cast<const double*>(&recb[jj]);
-                    q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
-                    rhob[u] = rho_s[jj];
-                } else { q0b[u] = self0; qvb[u] = selfv; rhob[u] = rho_i; }
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const bool ok = sl[u] != SLOT_NONE;
-                const Q4 q0 = q0b[u], qv = qvb[u];
-                const double rho_j = rhob[u];
-                const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
-                const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
-                const double r2 = dx * dx + dy * dy + dz * dz;
-                const double dot = dvx * dx + dvy * dy + dvz * dz;
-                double w = dot / sqrt(r2 + 0.01 * q0.d);                        // nsc:643
-                w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
-                const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
-                const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
-                pair_add(s_pi, ok ? -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab : 0.0);   // nsc:649
-                if (ok) maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);        // nsc:780
+            s_pi = pair_total(s_pi);
+            maxrel = fmax(maxrel, pair_swap(maxrel));
+            if (!half) {
+                Pi[i] = s_pi;
+                bc[i].Bw = fmax(ms_i, 0.0) * s_pi;                              // m Pi [t==0]  nsc:651
+                if (ms_i > 0.0) {                                               // gas only     nsc:782
+                    double ct = h_i / sqrt(maxrel);
+                    if (ct != ct) ct = 0.0;                                     // nan_to_num
+                    if (ct > DBL_MAX) ct = DBL_MAX;
+                    if (ct > 0.0) { const u64 cb = (u64)__double_as_longlong(ct); my_ct = cb < my_ct ? cb : my_ct; }
+                }
             }
         }
-        maxrel = fmax(maxrel, pair_swap(maxrel));
-        if (!half) {
-            Pi[i] = s_pi;
-            bc[i].Bw = fmax(ms_i, 0.0) * s_pi;                                  // m Pi [t==0]  nsc:651
-            if (ms_i > 0.0) {                                                   // gas only     nsc:782
-                double ct = h_i / sqrt(maxrel);
-                if (ct != ct) ct = 0.0;                                         // nan_to_num
-                if (ct > DBL_MAX) ct = DBL_MAX;
-                if (ct > 0.0) my_ct = (u64)__double_as_longlong(ct);
-            }
-        }
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -351,7 +423,50 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
 }
 
 // ---- pass 3: viscous acceleration + heat      nsc:651-654 --------------------------------------
-__global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+struct ViscAcc { double x, y, z, h; };
+template <bool FAST>
+__device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB], const double2* img,
+                                           const double* lc1, const RecB* __restrict__ recb,
+                                           const RecBC* __restrict__ bc, const int* __restrict__ nbr, size_t col0,
+                                           size_t colstep, const Q4& r0, const Q4& rv, double hi2, double ci,
+                                           double Bi) {
+    Q4 q0b[NB], qvb[NB];
+    double c1b[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (FAST || sl[u] < SLOT_OVER) {
+            q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);     // qv.d = Bw_j
+            c1b[u] = lc1[sl[u]];
+        } else if (sl[u] == SLOT_OVER) {
+            const int jj = nbr[col0 + u * colstep];
+            const double* qb = reinterpret_cast<const double*>(&recb[jj]);
+            q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
+            const double2 tt = *reinterpret_cast<const double2*>(&bc[jj]);
+            qvb[u].d = tt.x; c1b[u] = tt.y;
+        } else { q0b[u] = r0; qvb[u] = rv; c1b[u] = 0.0; }
+    }
+    if (FAST) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (!FAST && sl[u] == SLOT_NONE) continue;
+        const Q4 q0 = q0b[u], qv = qvb[u];
+        const double c1 = c1b[u], Bj = qv.d;
+        const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double r2 = r * r;
+        const double qj = q0.d - r2, qi = hi2 - r2;
+        const double cb = -6.0 * c1 * (qj * qj);
+        const double ca = ci * (qi * qi);
+        const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
+        const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
+        const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
+        a.x += bx; a.y += by; a.z += bz;
+        a.h += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
+    }
+}
+
+__global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int k, int nblk,
+                                                           const int* __restrict__ nbr,
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,
                                                            const int* __restrict__ qorder,
@@ -361,80 +476,77 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks {x y | z h2 | vx vy | vz Bw}, c1, tile
     double* lc1 = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lc1 + BLOB_S);
-    const int b = xcd_block(blockIdx.x, gridDim.x);
     const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const int p = b * BLOB_P + t;
-    const int i = (p < n) ? qorder[p] : 0;
     const double* bcd = reinterpret_cast<const double*>(bc);
-    stage<2>(img, lc1, tile, recb, bcd, 2, bcd + 1, 2, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
-    const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
-    const double* selfq = reinterpret_cast<const double*>(&recb[i]);
-    const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
-    const double mi = m[i];
-    __syncthreads();
-    if (p >= n) return;
-    Q4 r0 = self0, rv = selfv;
-    {
-        const unsigned sl0 = tile[t];
-        if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
-        else if (sl0 == SLOT_OVER) {
-            const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
-            r0 = gload4(rq); rv = gload4(rq + 4);
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const int i = (p < n) ? qorder[p] : 0;
+        stage<2>(img, lc1, tile, recb, bcd, 2, bcd + 1, 2, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
+        const double* selfq = reinterpret_cast<const double*>(&recb[i]);
+        const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
+        const double mi = m[i];
+        __syncthreads();
+        if (p < n) {
+            Q4 r0 = self0, rv = selfv;
+            {
+                const unsigned sl0 = tile[t];
+                if (sl0 < SLOT_OVER) { r0 = lload4(img, (int)sl0, 0); rv = lload4(img, (int)sl0, 1); }
+                else if (sl0 == SLOT_OVER) {
+                    const double* rq = reinterpret_cast<const double*>(&recb[nbr[p]]);
+                    r0 = gload4(rq); rv = gload4(rq + 4);
+                }
+            }
+            const double hi2 = self0.d, ci = -6.0 * bci.y, Bi = bci.x;
+            ViscAcc a{0.0, 0.0, 0.0, 0.0};
+            const int nm = KPAD(k) >> 1;
+            unsigned sl[NB];
+            load_slots(sl, tile, 0, half, t);
+            for (int m0 = 0; m0 < nm; m0 += NB) {
+                unsigned cur[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) cur[u] = sl[u];
+                if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);
+                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                if (all_staged(cur))
+                    visc_batch<true>(a, cur, img, lc1, recb, bc, nbr, col0, 2 * (size_t)npad, r0, rv, hi2, ci, Bi);
+                else
+                    visc_batch<false>(a, cur, img, lc1, recb, bc, nbr, col0, 2 * (size_t)npad, r0, rv, hi2, ci, Bi);
+            }
+            const double ax = pair_total(a.x), ay = pair_total(a.y), az = pair_total(a.z), heat = pair_total(a.h);
+            if (!half) {
+                va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
+                vh[i] = heat * mi / 2.0;                                        // nsc:654
+            }
         }
+        __syncthreads();
     }
-    const double hi2 = self0.d, ci = -6.0 * bci.y, Bi = bci.x;
-    double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
-    const int nm = (k + 1) >> 1;
-    for (int m0 = 0; m0 < nm; m0 += NB) {
-        unsigned sl[NB];
-        Q4 q0b[NB], qvb[NB];
-        double c1b[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int kk = 2 * (m0 + u) + half;
-            sl[u] = (kk < k) ? tile[kk * BLOB_P + t] : SLOT_NONE;
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            if (sl[u] < SLOT_OVER) {
-                q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1);     // qv.d = Bw_j
-                c1b[u] = lc1[sl[u]];
-            } else if (sl[u] == SLOT_OVER) {
-                const int jj = nbr[(size_t)(2 * (m0 + u) + half) * npad + p];
-                const double* qb = reinterpret_cast<const double*>(&recb[jj]);
-                q0b[u] = gload4(qb); qvb[u] = gload4(qb + 4);
-                const double2 tt = *reinterpret_cast<const double2*>(&bc[jj]);
-                qvb[u].d = tt.x; c1b[u] = tt.y;
-            } else { q0b[u] = self0; qvb[u] = selfv; c1b[u] = 0.0; }
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const bool ok = sl[u] != SLOT_NONE;
-            const Q4 q0 = q0b[u], qv = qvb[u];
-            const double c1 = c1b[u], Bj = qv.d;
-            const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
-            const double r = sqrt(dx * dx + dy * dy + dz * dz);
-            const double r2 = r * r;
-            const double qj = q0.d - r2, qi = hi2 - r2;
-            const double cb = -6.0 * c1 * (qj * qj);
-            const double ca = ci * (qi * qi);
-            const double bx = ok ? (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0 : 0.0;          // nsc:651
-            const double by = ok ? (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0 : 0.0;
-            const double bz = ok ? (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0 : 0.0;
-            pair_add(ax, bx); pair_add(ay, by); pair_add(az, bz);
-            pair_add(heat, ok ? bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c) : 0.0);   // nsc:653
-        }
-    }
-    if (half) return;
-    va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
-    vh[i] = heat * mi / 2.0;                                                    // nsc:654
 }
 
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
+// persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
+static int blob_grid(sphx_ctx* ctx, int nblk) {
+    if (ctx->blob_grid <= 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        int per = 2;
+        if (const char* e = getenv("SPHX_BLOB_WGS")) per = atoi(e) > 0 ? atoi(e) : 2;
+        ctx->blob_grid = ((cus * per + 7) / 8) * 8;
+    }
+    return nblk < ctx->blob_grid ? nblk : ctx->blob_grid;
+}
+
 static int blob_attr_once(sphx_ctx* ctx) {
     if (ctx->blob_attr_set) return SPHX_OK;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_pi_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_visc_kernel),
@@ -447,7 +559,33 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_density_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k,
+    if (const char* e = getenv("SPHX_BLOB_EXP")) {        // timing experiments, outputs discarded
+        SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
+        double* d = ctx->in_j.as<double>();
+        size_t lds = IMG_BYTES(64, k);
+        if (const char* l = getenv("SPHX_BLOB_EXP_LDS")) lds = (size_t)atoi(l);      // e.g. 100000: one workgroup per CU
+        for (int mode = 0; mode < 4; ++mode) {
+            if (!(atoi(e) & (1 << mode))) continue;
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            HIPCHK(hipEventRecord(e0, ctx->stream));
+#define BLOB_EXP_LAUNCH(M)                                                                                           \
+            hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), lds, ctx->stream, (int)n, (int)npad, \
+                               k, nblk, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,        \
+                               ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
+            if (mode == 0) BLOB_EXP_LAUNCH(0);
+            else if (mode == 1) BLOB_EXP_LAUNCH(1);
+            else if (mode == 2) BLOB_EXP_LAUNCH(2);
+            else BLOB_EXP_LAUNCH(3);
+            HIPCHK(hipEventRecord(e1, ctx->stream));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            fprintf(stderr, "[sphx] blob_density experiment %d (lds %zu): %.4f ms\n", mode, lds, ms);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        }
+    }
+    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->rec1.as<RecA>(), ctx->rho_s.as<double>(), ctx->rho.as<double>(),
                        ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>());
@@ -459,7 +597,7 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_pi_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k,
+    hipLaunchKernelGGL(blob_pi_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->recv.as<RecB>(), ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(),
                        ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(), ct_bits);
@@ -471,7 +609,7 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_visc_kernel, dim3(nblk), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k,
+    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->recv.as<RecB>(), ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),
                        ctx->vh.as<double>());

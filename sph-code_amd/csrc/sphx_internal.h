@@ -106,6 +106,7 @@ struct sphx_ctx {
     bool use_lds = true;            // run the step loop's passes out of LDS (needs blob order)
     bool blob_lists = false;        // slot lists valid for the current neighbour list
     bool blob_attr_set = false;
+    int blob_grid = 0;              // persistent workgroups of the LDS passes (0: not yet derived)
     int blob_slots = 1 << 20;       // distinct neighbours staged per workgroup (clamped to the image size)
     int map_nactive = 0;            // device API: callers' particles below this are computed
     DevBuf rho, rhod, nden, G, Pi, Bw, va, vh, ha, F;

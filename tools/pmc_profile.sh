@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel hardware counters of `bench.py` (run on the GPU box through gpurun):
-#   tools/pmc_profile.sh <out-prefix> [bench.py args...]
+#   [KREGEX='blob_.*'] tools/pmc_profile.sh <out-prefix> [bench.py args...]
 # One rocprofv3 --pmc pass per counter group (no trace domains beside --kernel-trace), CSV output
 # under gpurun_out/pmc_<prefix>/, summarised per kernel and per launch into
 # gpurun_out/<prefix>_pmc_per_launch.json by tools/pmc_summary.py.
@@ -19,7 +19,7 @@ GROUPS_=(
 )
 g=0
 for grp in "${GROUPS_[@]}"; do
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/g$g" -o pmc -- \
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace ${KREGEX:+--kernel-include-regex "$KREGEX"} --output-format csv -d "$OUT/g$g" -o pmc -- \
       python3 "$ROOT/bench.py" --no-cpu --steps 3 --warmup 1 "$@" > "$OUT/g$g.log" 2>&1 || echo "group $g failed (see $OUT/g$g.log)"
   g=$((g+1))
 done
