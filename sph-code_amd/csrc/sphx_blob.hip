@@ -244,6 +244,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
                                                               const int* __restrict__ qorder,
+                                                              const int* __restrict__ omap, int n_active,
                                                               const RecA* __restrict__ rec, double* rho_s,
                                                               double* rho, double* rhod, double* nden, double* G,
                                                               double* ha) {
@@ -261,9 +262,11 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
             for (int q = threadIdx.x; q < KPAD(k) * BLOB_P; q += BLOB_T) tile[q] = (u16)((q * 37 + b) % BLOB_S);
         const double* self = reinterpret_cast<const double*>(&rec[i]);
         const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
+        // outputs go to the caller's index o (device API: ghosts, o >= n_active, are candidates only)
+        const int o = (p < n) ? (omap ? omap[i] : i) : 0x7FFFFFFF;
         __syncthreads();
-        if (p < n && EXP == 1 && s0.a == 1.2345e-300) rho[i] = img[threadIdx.x].x;
-        if (p < n && EXP != 1) {
+        if (o < n_active && EXP == 1 && s0.a == 1.2345e-300) rho[o] = img[threadIdx.x].x;
+        if (o < n_active && EXP != 1) {
             double xr = s0.a, yr = s0.b, zr = s0.c;
             {
                 const unsigned sl0 = tile[t];
@@ -289,14 +292,14 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
             const double s_rho = pair_total(a.rho), s_rd = pair_total(a.rd), s_n = pair_total(a.n);
             const double gx = pair_total(a.gx), gy = pair_total(a.gy), gz = pair_total(a.gz);
             if (EXP == 3) {
-                if (s_rho + gx + s_n + s_rd + gy + gz == 1.2345e-300) rho[i] = 0.0;
+                if (s_rho + gx + s_n + s_rd + gy + gz == 1.2345e-300) rho[o] = 0.0;
             } else if (!half) {
-                rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
-                rho_s[i] = s_rho;
-                G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz;
-                ha[3 * (size_t)i + 0] = -gx / s_rho;                  // nsc:619
-                ha[3 * (size_t)i + 1] = -gy / s_rho;
-                ha[3 * (size_t)i + 2] = -gz / s_rho;
+                rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
+                rho_s[i] = s_rho;                                     // storage order: staged by pass 2
+                G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
+                ha[3 * (size_t)o + 0] = -gx / s_rho;                  // nsc:619
+                ha[3 * (size_t)o + 1] = -gy / s_rho;
+                ha[3 * (size_t)o + 2] = -gz / s_rho;
             }
         }
         __syncthreads();                                   // the image is rewritten by the next blob
@@ -347,10 +350,11 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
                                                          const u16* __restrict__ slot16,
                                                          const int* __restrict__ uniq,
                                                          const int* __restrict__ qorder,
+                                                         const int* __restrict__ omap, int n_active,
                                                          const RecB* __restrict__ recb,
                                                          const double* __restrict__ rho_s,
                                                          const RecSelf* __restrict__ selfr, RecBC* bc, double* Pi,
-                                                         u64* ct_bits) {
+                                                         double* BwOut, u64* ct_bits) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, BLOB_S doubles, slot tile
     __shared__ u64 sm[BLOB_T / 64];
     double* lrho = reinterpret_cast<double*>(img + 4 * BLOB_S);
@@ -366,8 +370,9 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
         const double rho_i = rho_s[i];
         const double* selfq = reinterpret_cast<const double*>(&recb[i]);
         const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
+        const int o = (p < n) ? (omap ? omap[i] : i) : 0x7FFFFFFF;
         __syncthreads();
-        if (p < n) {
+        if (o < n_active) {
             Q4 r0 = self0, rv = selfv;
             {
                 const unsigned sl0 = tile[t];
@@ -396,8 +401,10 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
             s_pi = pair_total(s_pi);
             maxrel = fmax(maxrel, pair_swap(maxrel));
             if (!half) {
-                Pi[i] = s_pi;
-                bc[i].Bw = fmax(ms_i, 0.0) * s_pi;                              // m Pi [t==0]  nsc:651
+                Pi[o] = s_pi;
+                const double bw = fmax(ms_i, 0.0) * s_pi;                       // m Pi [t==0]  nsc:651
+                bc[i].Bw = bw;
+                if (BwOut) BwOut[o] = bw;
                 if (ms_i > 0.0) {                                               // gas only     nsc:782
                     double ct = h_i / sqrt(maxrel);
                     if (ct != ct) ct = 0.0;                                     // nan_to_num
@@ -470,6 +477,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,
                                                            const int* __restrict__ qorder,
+                                                           const int* __restrict__ omap, int n_active,
                                                            const RecB* __restrict__ recb,
                                                            const RecBC* __restrict__ bc,
                                                            const double* __restrict__ m, double* va, double* vh) {
@@ -486,9 +494,10 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
         const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
         const double* selfq = reinterpret_cast<const double*>(&recb[i]);
         const Q4 self0 = gload4(selfq), selfv = gload4(selfq + 4);
-        const double mi = m[i];
+        const int o = (p < n) ? (omap ? omap[i] : i) : 0x7FFFFFFF;
+        const double mi = (o < n_active) ? m[o] : 0.0;                      // m in output order
         __syncthreads();
-        if (p < n) {
+        if (o < n_active) {
             Q4 r0 = self0, rv = selfv;
             {
                 const unsigned sl0 = tile[t];
@@ -516,8 +525,8 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
             }
             const double ax = pair_total(a.x), ay = pair_total(a.y), az = pair_total(a.z), heat = pair_total(a.h);
             if (!half) {
-                va[3 * (size_t)i + 0] = -ax; va[3 * (size_t)i + 1] = -ay; va[3 * (size_t)i + 2] = -az;
-                vh[i] = heat * mi / 2.0;                                        // nsc:654
+                va[3 * (size_t)o + 0] = -ax; va[3 * (size_t)o + 1] = -ay; va[3 * (size_t)o + 2] = -az;
+                vh[o] = heat * mi / 2.0;                                        // nsc:654
             }
         }
         __syncthreads();
@@ -572,7 +581,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
 #define BLOB_EXP_LAUNCH(M)                                                                                           \
             hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), lds, ctx->stream, (int)n, (int)npad, \
                                k, nblk, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,        \
-                               ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
+                               nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
             if (mode == 0) BLOB_EXP_LAUNCH(0);
             else if (mode == 1) BLOB_EXP_LAUNCH(1);
             else if (mode == 2) BLOB_EXP_LAUNCH(2);
@@ -587,7 +596,8 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
     }
     hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
-                       ctx->qorder, ctx->rec1.as<RecA>(), ctx->rho_s.as<double>(), ctx->rho.as<double>(),
+                       ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
+                       ctx->rho_s.as<double>(), ctx->rho.as<double>(),
                        ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -599,8 +609,9 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
     hipLaunchKernelGGL(blob_pi_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
-                       ctx->qorder, ctx->recv.as<RecB>(), ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(),
-                       ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(), ct_bits);
+                       ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
+                       ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(),
+                       ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct_bits);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -611,7 +622,8 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
     hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
-                       ctx->qorder, ctx->recv.as<RecB>(), ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),
+                       ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
+                       ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),
                        ctx->vh.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;

@@ -78,6 +78,8 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * sphx_pad64(n) * sizeof(int)));
     ctx->map_perm = ctx->perm.as<int>();
     ctx->qorder = nullptr;
+    ctx->blob_lists = false;
+    if (ctx->use_blob) SPHX_TRY(sphx_build_blob_order(ctx, n));     // queries and passes in blob order
     ctx->map_nactive = (int)n_owned;
     ctx->n = n;
     ctx->npad = sphx_pad64(n);
@@ -90,6 +92,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     int rc = sphx_knn(ctx, n, k, xs, ys, zs, ctx->perm.as<int>(), ctx->inv.as<int>(), hint,
                       rscale > 0.0 ? rscale : ctx->rscale, dist, o);
     ctx->knn_hint_by_id = false;
+    if (rc == SPHX_OK && ctx->qorder && ctx->use_lds) rc = sphx_blob_translate(ctx, n, k);
     return rc;
 }
 

@@ -193,7 +193,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->nden, (size_t)n * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
-    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_density(ctx, n, k);
+    if (ctx->qorder && ctx->blob_lists) return sphx_blob_density(ctx, n, k);
     if (const char* e = getenv("SPHX_PASS_EXP")) {        // timing experiment, outputs discarded
         const int mode = atoi(e);
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
@@ -310,7 +310,7 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
     SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
-    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_pi(ctx, n, k, ct);
+    if (ctx->qorder && ctx->blob_lists) return sphx_blob_pi(ctx, n, k, ct);
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
                        ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->qorder,
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->va, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
-    if (ctx->qorder && ctx->blob_lists && !ctx->map_perm) return sphx_blob_visc(ctx, n, k, m);
+    if (ctx->qorder && ctx->blob_lists) return sphx_blob_visc(ctx, n, k, m);
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), ctx->qorder,
