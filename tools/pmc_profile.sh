@@ -14,7 +14,8 @@ GROUPS_=(
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
-  "FETCH_SIZE WRITE_SIZE"
+  "FETCH_SIZE"
+  "WRITE_SIZE"
   "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM GRBM_GUI_ACTIVE"
 )
 g=0
