@@ -152,6 +152,20 @@ int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* points, cons
                      const double* mean_cross, double* accel_onto /* (n,3) */,
                      double* accel_reaction /* (n,3) */);
 
+/* AGB dust and gas return per star: calculate_interpolation, sph/config_helper.py:180-211, on the
+ * splines of interpolate_amounts (config_helper.py:138-178; RectBivariateSpline kx = ky = 1).
+ * Spline o has ntx[o] / nty[o] knots and (ntx[o]-2)*(nty[o]-2) coefficients; tx, ty, coeffs are the
+ * splines' arrays one after the other (SciPy's get_knots() / get_coeffs()).  x = metallicity,
+ * y = mass; arguments outside the knot range are clamped as FITPACK does.  dust[i, mapto[o]] =
+ * spline_o (a repeated target keeps the last spline), then / divisor and clipped at 0.
+ * gas_out (and composition, both (n, nspecies)) may be NULL.  nspecies 6..32, nspl <= 32.        */
+int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, const double* metallicities,
+                    int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                    const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                    int nspecies, const double* mu_specie, const double* composition,
+                    double solar_mass, double* dust_out /* (n,nspecies) */,
+                    double* gas_out /* (n,nspecies) */);
+
 /* ---- device-resident simulation state: the fused hot path of drv:217-491 ------------- *
  * upload once, step many times (search -> dt -> sums -> leapfrog, nothing leaves HBM),
  * download when needed.  Particle order on the device changes every step (cell sort);

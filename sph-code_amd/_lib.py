@@ -49,6 +49,8 @@ SIGNATURES = {
     "sphx_artificial_viscosity": (C.c_int, [_P, C.c_int64, C.c_int, _I] + [_D] * 9 + [C.c_double, _D, _D]),
     "sphx_crossing_time": (C.c_int, [_P, C.c_int64, C.c_int, _I, _D, _D, _D, _D]),
     "sphx_net_impulse": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _D, _D, _I, _D, _D, _D, _D]),
+    "sphx_agb_yields": (C.c_int, [_P, C.c_int64, _D, _D, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D, _D, _D,
+                                  C.POINTER(C.c_int32), C.c_double, C.c_int, _D, _D, C.c_double, _D, _D]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),

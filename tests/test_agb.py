@@ -1,0 +1,109 @@
+"""AGB dust-yield lookup (sph/config_helper.py:138-211).
+
+Golden data: tests/golden/agb_reference.npz - outputs of the reference's own interpolate_amounts /
+calculate_interpolation, run in the build container by tests/golden/make_golden_agb.py, together with
+the AGB tables (data) they were fitted on.  CPU tests pin the oracle; the GPU test checks the HIP
+kernel (through the C ABI) against both.  Tolerance: rtol 1e-13 (fp64, a handful of operations)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(HERE, "golden", "agb_reference.npz"))
+
+
+def _splines(g):
+    return list(g["tx"]), list(g["ty"]), list(g["coeffs"])
+
+
+def test_oracle_evaluates_like_the_reference_splines(g):
+    from oracle import agb_oracle as ao
+    Zg, Mg = np.meshgrid(g["grid_z"], g["grid_m"], indexing="ij")       # includes points outside the table
+    for o in range(len(g["coeffs"])):
+        v = ao.evaluate(g["tx"][o], g["ty"][o], g["coeffs"][o], Zg.ravel(), Mg.ravel()).reshape(Zg.shape)
+        np.testing.assert_allclose(v, g["grid_vals"][o], rtol=RTOL, atol=0)
+
+
+def test_oracle_calculate_interpolation_vs_reference(g):
+    from oracle import agb_oracle as ao
+    dust, gas = ao.calculate_interpolation(g["masses"], g["metallicities"], _splines(g), g["mu_specie"],
+                                           g["composition"], mapto=g["mapto"], divisor=float(g["divisor"]))
+    np.testing.assert_allclose(dust, g["dust_mass_created"], rtol=RTOL, atol=0)
+    np.testing.assert_allclose(gas, g["gas_mass_created"], rtol=RTOL, atol=0)
+    # reference quirks the restatement must keep: repeated targets, clamped masses, untouched species
+    assert (dust[:, [0, 1, 2, 3, 4, 5, 9, 14]] == 0).all()
+    kg = g["masses"] > 1e20                     # masses in kg: every lookup sits on the 7 M_sun edge
+    edge, _ = ao.calculate_interpolation(np.full(kg.sum(), 7.0), g["metallicities"][kg], _splines(g),
+                                         g["mu_specie"], g["composition"][kg])
+    assert np.array_equal(dust[kg], edge)
+
+
+def test_oracle_fit_reproduces_reference_knots(g):
+    """SciPy's fit on the stored tables gives the reference's knots and coefficients (single patch)."""
+    from oracle import agb_oracle as ao
+    tab = g["tables"].copy()
+    tab[tab <= 0.] = 1e-30
+    tx, ty, cf = ao.fit(tab)
+    assert all(len(t) == 4 for t in tx) and all(len(t) == 4 for t in ty)
+    np.testing.assert_allclose(np.array(cf), g["coeffs"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(np.array(tx), g["tx"], rtol=0, atol=0)
+
+
+def test_product_fit_matches_reference(g, tmp_path):
+    """sph_code_amd.agb.interpolate_amounts on a directory laid out like the reference's."""
+    import sph_code_amd.agb as agb
+    d = tmp_path / "agb_interp"
+    d.mkdir()
+    (tmp_path / "sph").mkdir()
+    masses = agb.AGB_masses
+    for f, table in zip(g["files"], np.swapaxes(g["tables"], 0, 1)):          # (metallicity, species, mass)
+        np.savetxt(d / str(f), np.column_stack([masses, table.T]))
+    splines, mapto, div = agb.interpolate_amounts(str(tmp_path / "sph"))
+    assert div == 3 and list(mapto) == list(g["mapto"])
+    for o, sp in enumerate(splines):
+        np.testing.assert_allclose(sp.get_coeffs(), g["coeffs"][o], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(sp.get_knots()[0], g["tx"][o])
+        np.testing.assert_allclose(sp.get_knots()[1], g["ty"][o])
+
+
+@pytest.mark.gpu
+def test_gpu_yields_vs_reference_and_oracle(g):
+    import sph_code_amd.agb as agb
+    from oracle import agb_oracle as ao
+    splines = [agb.Spline(g["tx"][o], g["ty"][o], g["coeffs"][o]) for o in range(len(g["coeffs"]))]
+    dust, gas = agb.calculate_interpolation(g["masses"], g["metallicities"], splines, g["mapto"], float(g["divisor"]),
+                                            g["mu_specie"], g["composition"])
+    np.testing.assert_allclose(dust, g["dust_mass_created"], rtol=RTOL, atol=0)
+    np.testing.assert_allclose(gas, g["gas_mass_created"], rtol=RTOL, atol=0)
+    # a true piecewise-bilinear table (s = 0: 8 x 27 knots) on many stars, against the oracle
+    tab = g["tables"].copy()
+    tab[tab <= 0.] = 1e-30
+    fine = agb.fit_tables(tab, s=0)
+    assert fine[0].get_knots()[1].size > 20
+    rs = np.random.RandomState(5)
+    n = 200000
+    m = rs.uniform(0.5, 8.0, n); z = rs.uniform(0.0, 0.06, n)
+    comp = rs.uniform(0.01, 1.0, (n, 15)); comp /= comp.sum(axis=1)[:, None]
+    dust, gas = agb.calculate_interpolation(m, z, fine, g["mapto"], 3, g["mu_specie"], comp)
+    spl = ([s.get_knots()[0] for s in fine], [s.get_knots()[1] for s in fine], [s.get_coeffs() for s in fine])
+    d0, g0 = ao.calculate_interpolation(m, z, spl, g["mu_specie"], comp, mapto=g["mapto"], divisor=3)
+    np.testing.assert_allclose(dust, d0, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(gas, g0, rtol=1e-12, atol=0)
+    only_dust, none = agb.calculate_interpolation(m[:10], z[:10], fine, g["mapto"], 3, g["mu_specie"])
+    assert none is None and np.array_equal(only_dust, dust[:10])
+
+
+@pytest.mark.gpu
+def test_gpu_yields_bad_arguments(g):
+    import sph_code_amd.agb as agb
+    splines = [agb.Spline(g["tx"][o], g["ty"][o], g["coeffs"][o]) for o in range(len(g["coeffs"]))]
+    with pytest.raises(Exception):
+        agb.calculate_interpolation([1.0], [0.01], splines, np.full(11, 99), 3, g["mu_specie"])
+    with pytest.raises(ValueError):
+        agb.calculate_interpolation([1.0, 2.0], [0.01], splines, g["mapto"], 3, g["mu_specie"])
