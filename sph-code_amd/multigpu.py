@@ -167,7 +167,7 @@ class LibBackend:
     def search(self, pos, n_owned, hint, mean_h):
         n = pos.shape[0]
         self.n_total = n
-        h = torch.zeros(n, dtype=torch.float64, device=pos.device)
+        h = torch.zeros(n, dtype=torch.float64, device=pos.device)      # ghosts' entries stay 0 until their halo
         self._chk(self.lib.sphx_dev_set_mean_h(self.ctx.h, float(mean_h)))
         self._chk(self.lib.sphx_dev_search(self.ctx.h, n, n_owned, self.k, self._p(pos), self._p(hint), 0.0,
                                            float(self.dist_bound), self._p(h)))

@@ -311,12 +311,15 @@ def test_incremental_search_is_exact():
     assert st["refresh_steps"] + st["rebuild_steps"] == nsteps
 
 
-@pytest.mark.parametrize("workload,n", [("polytrope", 20000), ("dusty_sphere", 6000)])
-def test_step_loop_variants_are_bit_identical(workload, n, monkeypatch):
+@pytest.mark.parametrize("workload,n,K", [("polytrope", 20000, 40), ("dusty_sphere", 6000, 40),
+                                          ("uniform_sphere", 3000, 7), ("uniform_sphere", 5000, 33),
+                                          ("polytrope", 9000, 64), ("uniform_cube", 40, 64)])
+def test_step_loop_variants_are_bit_identical(workload, n, K, monkeypatch):
     """The step loop's passes exist in three forms that must agree bit for bit: gathers in storage
     order (SPHX_BLOB=0), gathers in blob order (SPHX_LDS=0), neighbour records staged in LDS
     (default) - the last also with the image squeezed to 300 slots, so that part of the references
-    take the global-memory fallback."""
+    take the global-memory fallback.  K = 7 / 33: odd list lengths (the two lanes of a particle split the
+    list by parity); K = 64: the widest slot tile; n = 40 < K: lists with missing entries."""
     import sph_code_amd.ics as ics
     from sph_code_amd.sim import Simulation
     s0 = ics.WORKLOADS[workload](n)
@@ -325,7 +328,7 @@ def test_step_loop_variants_are_bit_identical(workload, n, monkeypatch):
                       ("storage_order", {"SPHX_BLOB": "0"})):
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
-        sim = Simulation(s0, n_neigh=40)          # a fresh context reads the switches
+        sim = Simulation(s0, n_neigh=K)           # a fresh context reads the switches
         sim.step(4)
         res[name] = sim.download()
         for k_ in env:
