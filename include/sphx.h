@@ -226,6 +226,17 @@ int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const double* mass, 
                   double* visc_heat);
 /* drv:233-238 and drv:460-491 on caller-order (n,3) arrays                                   */
 int sphx_dev_clamp(sphx_ctx* ctx, int64_t n, double* pos, double* vel);
+/* Halo / migration plumbing of the decomposed driver (sph_code_amd/multigpu.py): particles live in
+ * separate device arrays of 8-byte elements, field q being (n, widths[q]); what travels are rows of
+ * W = sum(widths) elements.  All pointers are device pointers (the pointer TABLES are host arrays).
+ *   pack_rows: rows[t,:] = fields[idx[t],:] for t < n            (idx NULL: identity)
+ *   regroup:   fields_out[t] = fields_in[sel[t]] for t < n_sel   (sel NULL: identity),
+ *              fields_out[n_sel + r] = rows[r] for r < n_rows.                                   */
+int sphx_dev_pack_rows(sphx_ctx* ctx, int64_t n, const int64_t* idx, int nf, const double* const* fields,
+                       const int32_t* widths, double* rows);
+int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel, int64_t n_rows, const double* rows,
+                     int nf, const double* const* fields_in, const int32_t* widths,
+                     double* const* fields_out);
 int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
                        double* E_internal, double* T, const double* mass, const double* mu,
                        const double* gamma, const double* ptype, const double* hydro_accel,

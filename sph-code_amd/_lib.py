@@ -68,6 +68,9 @@ SIGNATURES = {
     "sphx_dev_pi": (C.c_int, [_P] + [_P] * 4),
     "sphx_dev_visc": (C.c_int, [_P] + [_P] * 4),
     "sphx_dev_clamp": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "sphx_dev_pack_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
+    "sphx_dev_regroup": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "sphx_dev_integrate": (C.c_int, [_P, C.c_int64] + [_P] * 12 + [C.c_double]),
 }
 

@@ -268,3 +268,104 @@ extern "C" int sphx_sync(sphx_ctx* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }
+
+// ---- fused row packing / regrouping for the halo and migration protocol -----------------------
+// The driver keeps its particles as separate arrays (n,) / (n,3); what travels between ranks are
+// rows (one particle = W doubles).  Two kernels replace the dozens of small gather / concatenate
+// launches a tensor library needs for that:
+//   pack:     rows[t, :] = concat_f fields_f[idx[t], :]                  (idx == NULL: identity)
+//   regroup:  out_f[t]   = fields_f[sel[t]]           for t <  n_sel     (sel == NULL: identity)
+//             out_f[t]   = rows[t - n_sel, col_f ...] for t >= n_sel
+// Elements are copied as 8-byte words (double, or int64 ids).
+#define ROWS_MAX_FIELDS 16
+struct RowFields {
+    int nf, W;
+    const double* src[ROWS_MAX_FIELDS];
+    double* dst[ROWS_MAX_FIELDS];
+    int width[ROWS_MAX_FIELDS], col[ROWS_MAX_FIELDS];
+};
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(long long n, const long long* idx, RowFields f, double* rows) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * f.W) return;
+    const long long t = e / f.W;
+    const int c = (int)(e - t * f.W);
+    const long long i = idx ? idx[t] : t;
+    int q = 0;
+    while (q + 1 < f.nf && c >= f.col[q + 1]) ++q;
+    rows[e] = f.src[q][i * f.width[q] + (c - f.col[q])];
+}
+
+__global__ __launch_bounds__(256) void regroup_kernel(long long n_sel, long long n_rows, const long long* sel,
+                                                      const double* rows, RowFields f) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = n_sel + n_rows;
+    if (e >= n * f.W) return;
+    const long long t = e / f.W;
+    const int c = (int)(e - t * f.W);
+    int q = 0;
+    while (q + 1 < f.nf && c >= f.col[q + 1]) ++q;
+    double v;
+    if (t < n_sel) {
+        const long long i = sel ? sel[t] : t;
+        v = f.src[q][i * f.width[q] + (c - f.col[q])];
+    } else {
+        v = rows[(t - n_sel) * f.W + c];
+    }
+    f.dst[q][t * f.width[q] + (c - f.col[q])] = v;
+}
+
+static int row_fields(sphx_ctx* ctx, int nf, const double* const* src, double* const* dst, const int32_t* widths,
+                      RowFields* f) {
+    if (nf < 1 || nf > ROWS_MAX_FIELDS) return sphx_set_err(ctx, SPHX_E_ARG, "%d fields not in 1..%d", nf, ROWS_MAX_FIELDS);
+    f->nf = nf;
+    int col = 0;
+    for (int q = 0; q < nf; ++q) {
+        if (widths[q] < 1) return sphx_set_err(ctx, SPHX_E_ARG, "field %d has width %d", q, widths[q]);
+        f->src[q] = src ? src[q] : nullptr;
+        f->dst[q] = dst ? dst[q] : nullptr;
+        f->width[q] = widths[q];
+        f->col[q] = col;
+        col += widths[q];
+    }
+    f->W = col;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_pack_rows(sphx_ctx* ctx, int64_t n, const int64_t* idx, int nf, const double* const* fields,
+                                  const int32_t* widths, double* rows) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(fields); NEED(widths);
+    if (n < 0) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld < 0", (long long)n);
+    if (n == 0) return SPHX_OK;
+    NEED(rows);
+    HIPCHK(hipSetDevice(ctx->device));
+    RowFields f;
+    SPHX_TRY(row_fields(ctx, nf, fields, nullptr, widths, &f));
+    for (int q = 0; q < nf; ++q) NEED(fields[q]);
+    const long long tot = (long long)n * f.W;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n,
+                       (const long long*)idx, f, rows);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel, int64_t n_rows, const double* rows,
+                                int nf, const double* const* fields_in, const int32_t* widths,
+                                double* const* fields_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(widths); NEED(fields_out);
+    if (n_sel < 0 || n_rows < 0) return sphx_set_err(ctx, SPHX_E_ARG, "negative count");
+    if (n_sel + n_rows == 0) return SPHX_OK;
+    if (n_sel > 0) NEED(fields_in);
+    if (n_rows > 0) NEED(rows);
+    HIPCHK(hipSetDevice(ctx->device));
+    RowFields f;
+    SPHX_TRY(row_fields(ctx, nf, n_sel > 0 ? fields_in : nullptr, fields_out, widths, &f));
+    for (int q = 0; q < nf; ++q) NEED(fields_out[q]);
+    const long long tot = (long long)(n_sel + n_rows) * f.W;
+    hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (long long)n_sel, (long long)n_rows, (const long long*)sel, rows, f);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

@@ -108,14 +108,17 @@ class Exchanger:
         dist.all_gather(allc, mine)
         return [int(allc[p][self.rank]) for p in range(self.world)]
 
-    def rows(self, send_bufs, recv_counts, width, dtype=torch.float64):
+    def rows(self, send_bufs, recv_counts, width, dtype=torch.float64, into=None):
         """send_bufs[p]: (count_p, width) tensor for peer p (any device) -> list of received
-        (recv_counts[p], width) tensors on the compute device of send_bufs."""
+        (recv_counts[p], width) tensors on the compute device of send_bufs.  `into`: a contiguous
+        (sum(recv_counts), width) tensor on the communication device; peers' rows are then received
+        straight into its consecutive slices (which the returned list aliases)."""
         out = [None] * self.world
         if self.world == 1:
             return out
         ops, stage = [], []
         dev = None
+        o = 0
         for p in range(self.world):
             if p == self.rank:
                 continue
@@ -127,7 +130,11 @@ class Exchanger:
                 ops.append(dist.P2POp(dist.isend, t, p))
                 stage.append(t)
             if recv_counts[p] > 0:
-                r = torch.empty((recv_counts[p], width), dtype=dtype, device=self.comm_device)
+                if into is not None:
+                    r = into[o:o + recv_counts[p]]
+                    o += recv_counts[p]
+                else:
+                    r = torch.empty((recv_counts[p], width), dtype=dtype, device=self.comm_device)
                 ops.append(dist.P2POp(dist.irecv, r, p))
                 out[p] = r
         if ops:
@@ -163,6 +170,36 @@ class LibBackend:
 
     def clamp(self, pos, vel):
         self._chk(self.lib.sphx_dev_clamp(self.ctx.h, pos.shape[0], self._p(pos), self._p(vel)))
+
+    @staticmethod
+    def _table(tensors):
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        wid = (C.c_int32 * len(tensors))(*[1 if t.dim() == 1 else int(t.shape[1]) for t in tensors])
+        return arr, wid
+
+    def pack_rows(self, idx, fields):
+        """rows[t] = concatenated fields of particle idx[t] (one launch; include/sphx.h sphx_dev_pack_rows)."""
+        fields = [f.contiguous() for f in fields]
+        n = int(fields[0].shape[0] if idx is None else idx.numel())
+        W = sum(1 if f.dim() == 1 else int(f.shape[1]) for f in fields)
+        rows = torch.empty((n, W), dtype=torch.float64, device=self.device)
+        if n:
+            arr, wid = self._table(fields)
+            self._chk(self.lib.sphx_dev_pack_rows(self.ctx.h, n, self._p(idx), len(fields), arr, wid, self._p(rows)))
+        return rows
+
+    def regroup(self, sel, n_sel, rows, fields):
+        """New arrays: fields[sel] followed by the particles in `rows` (one launch; sphx_dev_regroup)."""
+        fields = [f.contiguous() for f in fields]
+        nr = 0 if rows is None else int(rows.shape[0])
+        n = n_sel + nr
+        outs = [torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=self.device) for f in fields]
+        if n:
+            arr, wid = self._table(fields)
+            oarr, _ = self._table(outs)
+            self._chk(self.lib.sphx_dev_regroup(self.ctx.h, n_sel, self._p(sel), nr,
+                                                self._p(rows.contiguous()) if nr else None, len(fields), arr, wid, oarr))
+        return outs
 
     def search(self, pos, n_owned, hint, mean_h):
         n = pos.shape[0]
@@ -246,6 +283,7 @@ class DistributedSim:
         self.halo_scale = halo_scale
         self.skin_frac = skin_frac          # plan is reused while displacements stay below skin/2
         self.w_plan, self.send_idx, self.recv_counts, self.pos_plan = None, None, None, None
+        self.send_cat = None
         self.grow = 1.0
         # coarse global grid for the need maps: global bounding box of the initial state + 25 %
         pmin = self.s["pos"].min(dim=0).values if n else torch.full((3,), 1e300, dtype=torch.float64, device=self.device)
@@ -328,22 +366,74 @@ class DistributedSim:
         recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
         return send_idx, recv_counts
 
-    def _halo(self, send_idx, recv_counts, owned_rows):
-        """owned_rows (n_owned, w) -> ghost rows (n_ghost, w), ghosts ordered by source rank."""
-        w = owned_rows.shape[1]
-        bufs = [None if ix is None else owned_rows[ix] for ix in send_idx]
-        got = self.ex.rows(bufs, recv_counts, w)
+    # rows <-> separate arrays.  Backends with fused kernels (LibBackend) do each in one launch; the
+    # tensor-library forms below are the specification (and what the CPU tests run).
+    @staticmethod
+    def _as_f64(t):
+        return t.view(torch.float64) if t.dtype == torch.int64 else t        # ids travel as raw 8-byte words
+
+    def _pack(self, idx, fields):
+        """(len(idx), W) rows of the particles idx (None: all) from the given (n,) / (n,w) fields."""
+        fields = [self._as_f64(f) for f in fields]
+        if hasattr(self.backend, "pack_rows"):
+            return self.backend.pack_rows(idx, fields)
+        rows = torch.cat([f if f.dim() == 2 else f[:, None] for f in fields], dim=1)
+        return rows if idx is None else rows[idx]
+
+    def _regroup(self, sel, n_sel, rows, fields):
+        """fields[sel] (None: the first n_sel as they are) followed by the particles in rows."""
+        dts = [f.dtype for f in fields]
+        f64 = [self._as_f64(f) for f in fields]
+        if hasattr(self.backend, "regroup"):
+            outs = self.backend.regroup(sel, n_sel, rows, f64)
+        else:
+            outs, c = [], 0
+            for f in f64:
+                w = 1 if f.dim() == 1 else f.shape[1]
+                own = f[:n_sel] if sel is None else f[sel]
+                if rows is not None and rows.shape[0]:
+                    g = rows[:, c] if f.dim() == 1 else rows[:, c:c + w]
+                    own = torch.cat([own, g], dim=0)
+                outs.append(own.contiguous())
+                c += w
+        return [o.view(torch.int64) if d == torch.int64 else o for o, d in zip(outs, dts)]
+
+    def _exchange(self, send_idx, recv_counts, fields, into=None, send_cat=None):
+        """Rows of `fields` for every peer's send list -> the received rows (n_recv, W), ordered by
+        source rank.  `into`: receive in place (a contiguous (n_recv, W) view on the compute device)."""
+        W = sum(1 if f.dim() == 1 else f.shape[1] for f in fields)
+        dev = fields[0].device
+        nrecv = sum(recv_counts)
+        if self.world == 1:
+            return into if into is not None else torch.zeros((0, W), dtype=torch.float64, device=dev)
+        if send_cat is None:
+            parts = [ix for ix in send_idx if ix is not None and ix.numel()]
+            send_cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        rows = self._pack(send_cat, fields)
+        bufs, o = [], 0
+        for ix in send_idx:
+            c = 0 if ix is None else int(ix.numel())
+            bufs.append(None if ix is None else rows[o:o + c])
+            o += c
+        direct = into is not None and into.device == self.comm_device and into.is_contiguous()
+        if into is None and dev == self.comm_device:
+            into = torch.empty((nrecv, W), dtype=torch.float64, device=dev)
+            direct = True
+        got = self.ex.rows(bufs, recv_counts, W, into=into if direct else None)
+        if direct:
+            return into
         parts = [g for g in got if g is not None]
-        if parts:
-            return torch.cat(parts, dim=0)
-        return torch.zeros((0, w), dtype=torch.float64, device=owned_rows.device)
+        res = torch.cat(parts, dim=0) if parts else torch.zeros((0, W), dtype=torch.float64, device=dev)
+        if into is not None:
+            into.copy_(res)
+            return into
+        return res
 
     # ------------------------------------------------------------------------------------------
     def _replan(self):
         """Migrate strays to their region's owner, then rebuild the send lists: every owned particle
         claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
-        self._reorder()
-        self._migrate()
+        self._reorder_and_migrate()
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
         # (a radius changes by at most twice the local displacement, so fast movers claim more)
@@ -354,24 +444,22 @@ class DistributedSim:
             self.send_idx, self.recv_counts = self._plan(self.w_plan)
         else:
             self.send_idx, self.recv_counts = [None], [0]
+        parts = [ix for ix in self.send_idx if ix is not None and ix.numel()]
+        self.send_cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=self.device)
         self.pos_plan = s["pos"].clone()
         self.stats["replans"] = self.stats.get("replans", 0) + 1
 
-    def _reorder(self):
-        """Put the owned arrays into the cell order of the last search (when the backend exposes
-        it): the library's gathers/scatters between caller order and cell order become nearly
-        sequential, as in the fused single-GPU loop."""
+    def _cell_order(self):
+        """Owned particles in the cell order of the last search (when the backend exposes it), or None.
+        Keeping the owned arrays in that order makes the library's gathers / scatters between caller
+        order and cell order nearly sequential, as in the fused single-GPU loop."""
         if self.last_ntotal is None or not hasattr(self.backend, "order"):
-            return
+            return None
         no = self.n_owned
         order = self.backend.order(self.last_ntotal)
         order = order[order < no]
-        if order.numel() != no:
-            return
-        for key in list(self.s):
-            self.s[key] = self.s[key][order].contiguous()
-        self.last = {k_: v[order].contiguous() for k_, v in self.last.items()}
         self.last_ntotal = None
+        return order if order.numel() == no else None
 
     def step(self, fixed_dt=0.0):
         """One decomposed pass of the hot path.
@@ -410,15 +498,9 @@ class DistributedSim:
             hint_owned = s["h"]
             mean_h = self.hmean_prev
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
-            owned_rows = torch.cat([s["pos"], s["vel"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
-                                    s["gam"][:, None], s["ptype"][:, None], s["h"][:, None]], dim=1)
-            g = self._halo(send_idx, recv_counts, owned_rows)
-            pos = torch.cat([s["pos"], g[:, 0:3]], dim=0).contiguous()
-            vel = torch.cat([s["vel"], g[:, 3:6]], dim=0).contiguous()
-            cat1 = lambda own, col: torch.cat([own, g[:, col]], dim=0).contiguous()
-            m, T, mu = cat1(s["m"], 6), cat1(s["T"], 7), cat1(s["mu"], 8)
-            gam, ptype = cat1(s["gam"], 9), cat1(s["ptype"], 10)
-            hint = None if hint_owned is None else cat1(hint_owned, 11)
+            state_fields = [s["pos"], s["vel"], s["m"], s["T"], s["mu"], s["gam"], s["ptype"], s["h"]]
+            g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
+            pos, vel, m, T, mu, gam, ptype, hint = self._regroup(None, no, g, state_fields)
             h = be.search(pos, no, hint, mean_h)
             bad = float((h[:no] + 2.0 * D > self.w_plan).any()) if no else 0.0
             if self._allreduce_max(bad) < 0.5:
@@ -431,18 +513,15 @@ class DistributedSim:
             self._replan()
             D = 0.0
             self.stats["redo"] += 1
-        # ---- halo phase 2: ghosts' h_j ----------------------------------------------------------
-        gh = self._halo(send_idx, recv_counts, h[:no, None])
-        h = torch.cat([h[:no], gh[:, 0]], dim=0).contiguous()
+        # ---- halo phases 2-4: 8 B per ghost, received straight into the tail of the (n_total,)
+        # array the library just filled for the owned particles --------------------------------
+        tail = lambda a: a[no:].view(ng, 1)
+        self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)            # h_j
         be.prep(pos, vel, m, h, T, mu, gam, ptype)
         rho, nden, ha = be.density()
-        # ---- halo phase 3: ghosts' rho_j --------------------------------------------------------
-        gr = self._halo(send_idx, recv_counts, rho[:no, None])
-        rho = torch.cat([rho[:no], gr[:, 0]], dim=0).contiguous()
+        self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)        # rho_j
         bw, ct = be.pi(rho)
-        # ---- halo phase 4: ghosts' m Pi_j -------------------------------------------------------
-        gb = self._halo(send_idx, recv_counts, bw[:no, None])
-        bw = torch.cat([bw[:no], gb[:, 0]], dim=0).contiguous()
+        self._exchange(send_idx, recv_counts, [bw[:no]], into=tail(bw), send_cat=self.send_cat)          # m Pi_j
         va, vh = be.visc(bw, m)
         # ---- dt: global minimum crossing time (nsc:786, drv:222-229) ----------------------------
         # one host synchronisation for this step's scalars: crossing time, max and mean h
@@ -477,41 +556,45 @@ class DistributedSim:
         self.stats["ghosts"] += ng
 
     # ------------------------------------------------------------------------------------------
-    def _migrate(self):
-        """Particles that left the region move to their new owner (all owned fields)."""
-        if self.world == 1:
-            return
+    MIG_FIELDS = ("pos", "vel", "acc", "m", "T", "mu", "gam", "ptype", "E", "h", "gid")
+
+    def _reorder_and_migrate(self):
+        """Owned arrays into cell order, strays to their region's owner, arrivals appended: the kept
+        particles are gathered once (one launch with a fused backend)."""
         s = self.s
-        owner = region_of(s["pos"], self.lo, self.hi)
-        stay = owner == self.rank
-        leave = torch.nonzero(~stay).flatten()                 # usually a handful: group them by new owner
-        own_l = owner[leave]
-        order = torch.argsort(own_l, stable=True)
-        leave = leave[order]
-        cnt = torch.bincount(own_l, minlength=self.world).tolist() if leave.numel() else [0] * self.world
-        send_idx, o = [], 0
-        for p in range(self.world):
-            send_idx.append(None if p == self.rank else leave[o:o + cnt[p]])
-            o += cnt[p]
-        recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
-        if not self.last:
-            z = torch.zeros(s["pos"].shape[0], dtype=torch.float64, device=s["pos"].device)
+        n = self.n_owned
+        if not self.last or self.last["rho"].shape[0] != n:
+            z = torch.zeros(n, dtype=torch.float64, device=self.device)
             self.last = dict(rho=z, nden=z.clone(), visc_heat=z.clone())
-        extra = [self.last[k_][:, None] for k_ in ("rho", "nden", "visc_heat")]
-        rows = torch.cat([s["pos"], s["vel"], s["acc"], s["m"][:, None], s["T"][:, None], s["mu"][:, None],
-                          s["gam"][:, None], s["ptype"][:, None], s["E"][:, None], s["h"][:, None],
-                          s["gid"].to(torch.float64)[:, None]] + extra, dim=1)
-        got = self._halo(send_idx, recv_counts, rows)
-        keep = rows[stay]
-        allr = torch.cat([keep, got], dim=0) if got.shape[0] else keep
-        self.stats["migrated"] += int(got.shape[0])
-        s["pos"], s["vel"], s["acc"] = (allr[:, 0:3].contiguous(), allr[:, 3:6].contiguous(),
-                                        allr[:, 6:9].contiguous())
-        for i, nm in enumerate(("m", "T", "mu", "gam", "ptype", "E", "h")):
-            s[nm] = allr[:, 9 + i].contiguous()
-        s["gid"] = allr[:, 16].round().to(torch.int64)
-        self.last = dict(rho=allr[:, 17].contiguous(), nden=allr[:, 18].contiguous(),
-                         visc_heat=allr[:, 19].contiguous())
+        fields = [s[k_] for k_ in self.MIG_FIELDS] + [self.last[k_] for k_ in ("rho", "nden", "visc_heat")]
+        order = self._cell_order()
+        got = None
+        sel = order
+        if self.world > 1:
+            owner = region_of(s["pos"], self.lo, self.hi)
+            stay = owner == self.rank
+            leave = torch.nonzero(~stay).flatten()             # usually a handful: group them by new owner
+            own_l = owner[leave]
+            o2 = torch.argsort(own_l, stable=True)
+            leave = leave[o2]
+            cnt = torch.bincount(own_l, minlength=self.world).tolist() if leave.numel() else [0] * self.world
+            send_idx, o = [], 0
+            for p in range(self.world):
+                send_idx.append(None if p == self.rank else leave[o:o + cnt[p]])
+                o += cnt[p]
+            recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
+            if leave.numel() or sum(recv_counts):
+                got = self._exchange(send_idx, recv_counts, fields)
+                self.stats["migrated"] += int(got.shape[0])
+                if leave.numel():
+                    sel = torch.nonzero(stay).flatten() if order is None else order[stay[order]]
+        if sel is None and (got is None or got.shape[0] == 0):
+            return                                             # nothing moved, no order to apply
+        n_sel = n if sel is None else int(sel.numel())
+        new = self._regroup(sel, n_sel, got, fields)
+        for k_, v in zip(self.MIG_FIELDS, new):
+            s[k_] = v
+        self.last = dict(rho=new[-3], nden=new[-2], visc_heat=new[-1])
 
     def owned_numpy(self):
         """This rank's owned particles as NumPy arrays keyed like the single-GPU download."""
