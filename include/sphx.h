@@ -70,6 +70,7 @@ typedef struct sphx_stats {
     int64_t refresh_steps; /* steps whose kNN came from the Verlet lists         */
     int64_t rebuild_steps; /* steps with cell sort + full search                 */
     double  cell_size;     /* edge of the last grid's cells                     */
+    double  ms_gravity;    /* self-gravity (0 unless sphx_state_set_gravity)    */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -152,6 +153,11 @@ int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* points, cons
                      const double* mean_cross, double* accel_onto /* (n,3) */,
                      double* accel_reaction /* (n,3) */);
 
+/* Softened direct-sum gravity on host arrays: accel (n,3).  sizes != NULL: eps = median(sizes)
+ * (nsc:358, as grav_force_calculation_new(mass, points, sizes) takes it), else eps = softening.   */
+int sphx_gravity_direct(sphx_ctx* ctx, int64_t n, const double* mass, const double* points,
+                        const double* sizes, double softening, double G, double* accel);
+
 /* AGB dust and gas return per star: calculate_interpolation, sph/config_helper.py:180-211, on the
  * splines of interpolate_amounts (config_helper.py:138-178; RectBivariateSpline kx = ky = 1).
  * Spline o has ntx[o] / nty[o] knots and (ntx[o]-2)*(nty[o]-2) coefficients; tx, ty, coeffs are the
@@ -180,6 +186,11 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
  * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
  * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
 int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
+/* Self-gravity inside the step loop (drv:448-449,477): mode 1 = direct summation with Plummer
+ * softening eps = median(h) of the step (nsc:358), G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2)
+ * summed over ALL particles - the sum the reference's tree approximates (sphx_gravity_direct).
+ * O(N^2): meant for N up to a few 10^5.  mode 0 switches it off.  Call after sphx_state_upload. */
+int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G);
 /* One or more passes of the hot path.  k = N_NEIGH, dist = distance_upper_bound of
  * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);
  * fixed_dt > 0 overrides the crossing-time rule (drv:225-229).                           */

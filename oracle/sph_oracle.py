@@ -383,9 +383,10 @@ def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type,
         vn = np.sqrt(np.sum(v ** 2, axis=1)); an = np.sqrt(np.sum(visc ** 2, axis=1))
         lim = (vn - an * dt) < 0                                               # drv:475
         visc = np.where(lim[:, None], -v / dt, visc)
-        total = pressure_accel + visc
         if grav_accel is not None:
-            total = total + grav_accel                                         # drv:477
+            total = grav_accel + pressure_accel + visc                         # drv:477
+        else:
+            total = pressure_accel + visc
         p = p + (total * dt ** 2) / 2. + v * dt                                # drv:481
         v = v + (total + old) / 2. * dt                                        # drv:482-486
         E = np.nan_to_num(E_internal) + np.nan_to_num(vh * dt)                 # drv:490
@@ -393,8 +394,27 @@ def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type,
     return p, v, total, E, T
 
 
+G_NEWTON = 6.67430e-11        # scipy.constants.G (nsc:21)
+
+
+def gravity_direct(points, mass, softening, G=G_NEWTON, chunk=512):
+    """The sum the reference's tree gravity (nsc:252-415) approximates: every particle as its own
+    monopole, Plummer-softened as at nsc:385:  G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2)."""
+    p = np.asarray(points, dtype=np.float64)
+    m = np.asarray(mass, dtype=np.float64)
+    out = np.zeros_like(p)
+    e2 = float(softening) ** 2
+    for a in range(0, len(p), chunk):
+        d = p[None, :, :] - p[a:a + chunk, None, :]                    # (c, n, 3)
+        r2 = np.sum(d * d, axis=2) + e2
+        with np.errstate(all="ignore"):
+            w = np.where(r2 > 0, m[None, :] / (r2 * np.sqrt(r2)), 0.0)
+        out[a:a + chunk] = G * np.sum(w[:, :, None] * d, axis=1)
+    return out
+
+
 def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1,
-         fixed_dt=0.0, with_drag=False):
+         fixed_dt=0.0, with_drag=False, with_gravity=False, grav_G=None):
     """One pass of the hot path: search -> dt -> sums -> leapfrog update.
 
     state: dict with points, velocities, mass, particle_type, f_un, T, mu_array, gamma_array,
@@ -411,6 +431,8 @@ def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, 
         fu = np.ones((len(p), 1))
     ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, fu, s["particle_type"],
                                                    s["T"], s["mu_array"], s["gamma_array"], v)
+    if with_gravity:                                                           # drv:448-449, nsc:358
+        grav_accel = gravity_direct(p, s["mass"], np.median(h), G=G_NEWTON if grav_G is None else grav_G)
     drag = None
     if with_drag:                                                              # drv:455
         onto, react = net_impulse(p, s["mass"], h, v, s["particle_type"], nb, s["f_un"])

@@ -21,7 +21,7 @@ class SphxStats(C.Structure):
                                           "ms_visc", "ms_integrate", "ms_total")] + \
                [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
                                          "rebuild_steps")] + \
-               [("cell_size", C.c_double)]
+               [("cell_size", C.c_double), ("ms_gravity", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -53,6 +53,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_int32), C.c_double, C.c_int, _D, _D, C.c_double, _D, _D]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
+    "sphx_state_set_gravity": (C.c_int, [_P, C.c_int, C.c_double]),
+    "sphx_gravity_direct": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),
     "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
     "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsphx.so")
 SOURCES = ["sphx_api.hip", "sphx_grid.hip", "sphx_knn.hip", "sphx_sums.hip", "sphx_integrate.hip",
-           "sphx_loopforms.hip", "sphx_dev.hip", "sphx_refresh.hip", "sphx_blob.hip", "sphx_agb.hip"]
+           "sphx_loopforms.hip", "sphx_dev.hip", "sphx_refresh.hip", "sphx_blob.hip", "sphx_agb.hip", "sphx_gravity.hip"]
 HEADERS = [os.path.join(CSRC, "sphx_internal.h"), os.path.join(CSRC, "sphx_wave.h"),
            os.path.join(os.path.dirname(HERE), "include", "sphx.h")]
 

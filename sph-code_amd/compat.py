@@ -209,3 +209,19 @@ def net_impulse(points, mass, sizes, velocities, particle_type, neighbor, f_un):
                                    dp(f64(sizes, (n,))), dp(f64(velocities, (n, 3))),
                                    dp(f64(particle_type, (n,))), ip(nb), dp(mgm), dp(mcs), dp(onto), dp(react)))
     return onto, react
+
+
+def grav_force_direct(mass, points, sizes, G=6.67430e-11):
+    """Softened direct-sum self-gravity, (n,3): G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2) over all j,
+    eps = median(sizes) - the call shape of nsc.grav_force_calculation_new(mass, points, sizes) (nsc:252,
+    softening nsc:358,385).  NOT that function's result: the reference sums a few kd-tree monopoles and
+    cannot be run for comparison; this is the exact sum such a tree approximates."""
+    c = context()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    m = np.ascontiguousarray(mass, dtype=np.float64)
+    h = np.ascontiguousarray(sizes, dtype=np.float64)
+    out = np.empty((n, 3))
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+    c.check(c.lib.sphx_gravity_direct(c.h, n, dp(m), dp(pts), dp(h), 0.0, float(G), dp(out)))
+    return out

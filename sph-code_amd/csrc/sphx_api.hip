@@ -101,7 +101,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
+                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -315,6 +315,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->npad = sphx_pad64(n);
     ctx->has_state = true;
     ctx->drag = false;
+    ctx->gravity = 0;
     ctx->list_valid = false;
     ctx->clip_valid = false;
     ctx->h_clip = 0.0;
@@ -336,6 +337,15 @@ extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass,
     HIPCHK(hipMemcpyAsync(ctx->st.mcs.p, mean_cross, nb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->drag = true;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_gravity before sphx_state_upload");
+    if (mode != 0 && mode != 1) return sphx_set_err(ctx, SPHX_E_ARG, "gravity mode %d not in {0, 1}", mode);
+    ctx->gravity = mode;
+    ctx->grav_G = G;
     return SPHX_OK;
 }
 
@@ -426,6 +436,14 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                 s.mcs.as<double>()));
     HIPCHK(hipEventRecord(ev[6], ctx->stream));
+    if (ctx->gravity == 1) {                     // drv:448-449; softening = median(h), nsc:358
+        SPHX_TRY(sphx_ensure(ctx, ctx->grav, (size_t)n * 3 * sizeof(double)));
+        double* eps = ctx->scal.as<double>() + SC_GRAV_EPS;
+        SPHX_TRY(sphx_median(ctx, n, s.hprev.as<double>(), eps));
+        SPHX_TRY(sphx_gravity_launch(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), 1,
+                                     s.m.as<double>(), eps, 0.0, ctx->grav_G, nullptr, ctx->grav.as<double>()));
+    }
+    HIPCHK(hipEventRecord(ev[8], ctx->stream));
     SPHX_TRY(sphx_compute_dt(ctx, first, fixed_dt));
     SPHX_TRY(sphx_integrate(ctx, n));
     HIPCHK(hipEventRecord(ev[7], ctx->stream));
@@ -442,6 +460,11 @@ static int collect_stats(sphx_ctx* ctx) {
     HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[7]));
     sphx_stats& st = ctx->stats;
     st.ms_grid += ms[0]; st.ms_search += ms[1]; st.ms_prep += ms[2]; st.ms_density += ms[3];
+    float mg = 0.f, mi = 0.f;
+    HIPCHK(hipEventElapsedTime(&mg, ev[6], ev[8]));
+    HIPCHK(hipEventElapsedTime(&mi, ev[8], ev[7]));
+    ms[6] = mi;
+    st.ms_gravity += mg;
     st.ms_pi += ms[4]; st.ms_visc += ms[5]; st.ms_integrate += ms[6]; st.ms_total += tot;
     st.steps += 1;
     st.n = ctx->n;

@@ -160,6 +160,7 @@ struct IntegArgs {
     const double *m, *mu, *gam, *ptype;
     const double *ha, *va, *vh;                        // hydro_update outputs (reference sign)
     const double *rho, *rhod, *drag_on, *drag_re;      // drag terms (drag_on == nullptr: none)
+    const double* grav;                                // self-gravity (nullptr: none)
     const double* dt;
     double m_h, kB;
 };
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     double* A[3] = {a.ax, a.ay, a.az};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double tot = pa[c] + vis[c];                    // drv:477 (gravity: out of scope)
+        // drv:477: grav_accel + pressure_accel + visc_accel, added left to right
+        const double tot = a.grav ? (a.grav[3 * (size_t)i + c] + pa[c]) + vis[c] : pa[c] + vis[c];
         const double old = A[c][i];
         P[c][i] = P[c][i] + (tot * (dt * dt)) / 2.0 + v[c] * dt;   // drv:481
         V[c][i] = v[c] + (tot + old) / 2.0 * dt;              // drv:482-486
@@ -215,6 +217,7 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n) {
     a.rho = ctx->rho.as<double>(); a.rhod = ctx->rhod.as<double>();
     a.drag_on = ctx->drag ? ctx->drag_on.as<double>() : nullptr;
     a.drag_re = ctx->drag ? ctx->drag_re.as<double>() : nullptr;
+    a.grav = ctx->gravity ? ctx->grav.as<double>() : nullptr;
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);

@@ -86,6 +86,9 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
+    int gravity = 0;              // 1: direct-sum self-gravity each step (sphx_state_set_gravity)
+    double grav_G = 0.0;
+    DevBuf grav, grav_sort, grav_tmp;   // (n,3) accelerations, sorted h, radix-sort scratch
     // ---- Verlet refresh (sphx_refresh.hip) ----
     DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current
     bool list_valid = false, use_verlet = false;   // opt-in (sphx_set_incremental): pays only for slow drift
@@ -167,6 +170,7 @@ enum {
     SC_DISP2 = 5,     // u64: bits of the max squared displacement since the Verlet list was built
     SC_NFAIL = 6,     // u64: particles whose refreshed kNN could not be proven exact
     SC_HCNT = 7,      // f64: number of h values in SC_HSUM
+    SC_GRAV_EPS = 8,  // f64: gravitational softening = median(h) of this step (nsc:358)
     SC_NSLOTS = 16
 };
 
@@ -174,6 +178,10 @@ enum {
 // grid
 int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
               double out_minmax[13], bool use_clip);
+int sphx_median(sphx_ctx* ctx, int64_t n, const double* v, double* out_dev);
+int sphx_gravity_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z, int ps,
+                        const double* m, const double* eps_dev, double eps, double G, const int* omap,
+                        double* acc);
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);

@@ -15,7 +15,7 @@ from ._lib import dp, f64
 
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
-                 incremental=False, with_drag=False):
+                 incremental=False, with_drag=False, gravity=None, G=6.67430e-11):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -34,6 +34,10 @@ class Simulation:
             dp(f64(state["particle_type"], (n,))), dp(fu), dp(f64(state["T"], (n,))),
             dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
             dp(f64(state["E_internal"], (n,))), dp(acc)))
+        if gravity is not None:
+            if gravity != "direct":
+                raise ValueError("gravity must be None or 'direct'")
+            c.check(c.lib.sphx_state_set_gravity(c.h, 1, float(G)))
         if with_drag:
             # per-particle mean grain mass / cross-section as nsc.net_impulse forms them (nsc:720-726)
             from . import compat
