@@ -8,10 +8,12 @@
 // empty).  Each pass then fetches every distinct record ONCE per workgroup into an LDS image
 // (~5 gathers per particle instead of 40) and runs its neighbour loop out of LDS.
 //
-// Two lanes serve one particle: lane 2t sums the even list positions, lane 2t+1 the odd ones, and
-// the two partial sums are added at the end (one DPP exchange) - the same fixed order the gather
-// kernels of sphx_sums.hip use, so the results are bit-identical to theirs.  256 threads per workgroup, two workgroups per CU (LDS-bound):
-// two waves per SIMD hide LDS latency, and one workgroup stages while the other computes.
+// LPP = 4 lanes serve one particle: lane 4t+q sums the list positions k = q mod 4, and the four
+// partial sums are added at the end as (p0 + p1) + (p2 + p3) by two DPP exchanges - the same fixed
+// order the gather kernels of sphx_sums.hip use, so the results are bit-identical to theirs.  512
+// threads per workgroup, two workgroups per CU (LDS-bound): four waves per SIMD hide LDS latency
+// (two lanes per particle, i.e. two waves per SIMD, measured 10 % slower), and one workgroup stages
+// while the other computes.
 //
 // LDS image: BLOB_S slots; a record is kept as 16-byte chunks, chunk c of slot s at
 // (c * BLOB_S + s) * 16, so one ds_read_b128 of 16 lanes meets 16 bank-quads selected by s mod 16.
@@ -26,7 +28,9 @@
 #include <stdio.h>
 
 #define BLOB_P 128                  // particles per workgroup
-#define BLOB_T 256                  // threads per workgroup (two lanes per particle)
+#define BLOB_T 256                  // threads of the dedup kernel (two per particle)
+#define LPP SPHX_SUM_PARTS           // lanes per particle in the passes = partial sums per total
+#define PASS_T (BLOB_P * LPP)       // threads per workgroup of the passes
 #define BLOB_S 960                  // hash-table entries = image slots
 #define BLOB_PROBES 96
 #define SLOT_NONE 0xFFFFu           // no neighbour (list shorter than K)
@@ -120,6 +124,26 @@ __device__ __forceinline__ Q4 lload4(const double2* img, int s, int c2) {
     const double2 hi = img[(2 * c2 + 1) * BLOB_S + s];
     return Q4{lo.x, lo.y, hi.x, hi.y};
 }
+// sqrt for the distances of the neighbour loops: the library's correctly rounded sequence (v_rsq_f64
+// seed, two coupled Newton steps on g ~ sqrt(x), h ~ 1/(2 sqrt(x)), residual corrections) without its
+// exponent rescaling and class checks - squared distances here are 0 or sit mid-range (1e20..1e45 m^2).
+// Measured: library sqrt = 18 fp64-multiply issue slots, this = 11 (a pass spends ~80 per neighbour).
+// Bit-identical to sqrt() on that range (test_step_loop_variants_are_bit_identical compares against
+// the gather kernels, which call sqrt()).
+__device__ __forceinline__ double sqrt_mid(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d1, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
 // the value held by the other lane of the pair (lane ^ 1), moved inside the VALU
 __device__ __forceinline__ double pair_swap(double v) {
     const long long b = __double_as_longlong(v);
@@ -127,12 +151,28 @@ __device__ __forceinline__ double pair_swap(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// even-position partial sum + odd-position partial sum (valid in both lanes of the pair)
-__device__ __forceinline__ double pair_total(double acc) { return acc + pair_swap(acc); }
+__device__ __forceinline__ double pair_swap2(double v) {                                   // lane ^ 2
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x4E, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// total of the particle's LPP partial sums, in the fixed order (p0 + p1) [+ (p2 + p3)] that the gather
+// kernels use as well (valid in every lane of the group)
+__device__ __forceinline__ double group_total(double acc) {
+    acc = acc + pair_swap(acc);
+    if (LPP == 4) acc = acc + pair_swap2(acc);
+    return acc;
+}
+__device__ __forceinline__ double group_max(double v) {
+    v = fmax(v, pair_swap(v));
+    if (LPP == 4) v = fmax(v, pair_swap2(v));
+    return v;
+}
 
-#define NSTAGE ((BLOB_S + BLOB_T - 1) / BLOB_T)
-#define NB 4        // neighbours in flight per lane (one batch = 2 * NB list positions)
-#define KPAD(k) ((((k) + 2 * NB - 1) / (2 * NB)) * (2 * NB))      // slot tile rows: whole batches
+#define NSTAGE ((BLOB_S + PASS_T - 1) / PASS_T)
+#define NB (8 / LPP) // neighbours in flight per lane (one batch = 8 list positions)
+#define KPAD(k) ((((k) + 7) / 8) * 8)      // slot tile rows: whole batches
 #define IMG_BYTES(per_slot, k) ((size_t)BLOB_S * (per_slot) + (size_t)KPAD(k) * BLOB_P * sizeof(u16))
 
 // Fill the workgroup's LDS: slot lists (16-B pieces; rows k..KPAD(k) read as "no neighbour") and the
@@ -148,11 +188,11 @@ __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, con
     int ju[NSTAGE];
 #pragma unroll
     for (int r = 0; r < NSTAGE; ++r) {
-        const int s = threadIdx.x + r * BLOB_T;
+        const int s = threadIdx.x + r * PASS_T;
         ju[r] = (s < BLOB_S) ? uq[s] : -1;
     }
     const int pieces = KPAD(k) * (BLOB_P / 8);
-    for (int q = threadIdx.x; q < pieces; q += BLOB_T) {
+    for (int q = threadIdx.x; q < pieces; q += PASS_T) {
         const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
         uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         if (kk < k) v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
@@ -170,7 +210,7 @@ __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, con
     }
 #pragma unroll
     for (int r = 0; r < NSTAGE; ++r) {
-        const int s = threadIdx.x + r * BLOB_T;
+        const int s = threadIdx.x + r * PASS_T;
         if (ju[r] >= 0) {
             if (NSIDE == 2) c[r][3].y = e0[r];
             img[0 * BLOB_S + s] = c[r][0]; img[1 * BLOB_S + s] = c[r][1];
@@ -205,7 +245,7 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
         if (!FAST && sl[u] == SLOT_NONE) continue;
         const Q4 q0 = q0b[u], q1 = q1b[u];
         const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);   // nsc:586
+        const double r = sqrt_mid(dx * dx + dy * dy + dz * dz);   // nsc:586
         const double r2 = r * r;                              // nsc:588 squares the rounded distance
         const double qj = q0.d - r2;
         const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
@@ -226,7 +266,7 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
 // the lane's slot numbers for batch m0 (tile rows beyond k hold SLOT_NONE)
 __device__ __forceinline__ void load_slots(unsigned (&sl)[NB], const u16* tile, int m0, int half, int t) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) sl[u] = tile[(2 * (m0 + u) + half) * BLOB_P + t];
+    for (int u = 0; u < NB; ++u) sl[u] = tile[(LPP * (m0 + u) + half) * BLOB_P + t];
 }
 __device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
     unsigned worst = sl[0];
@@ -239,7 +279,7 @@ __device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
 // EXP != 0: timing experiments on an extra, discarded launch (SPHX_BLOB_EXP): 1 = staging only,
 // 2 = neighbour loop only (image not filled), 3 = both but no global stores at the end.
 template <int EXP>
-__global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int n, int npad, int k, int nblk,
                                                               const int* __restrict__ nbr,
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
@@ -250,7 +290,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
                                                               double* ha) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
     u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
-    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     // persistent workgroups (two per CU): blob after blob, no dispatch gap between them
     for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
         const int b = xcd_block(bi, nblk);
@@ -259,7 +299,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
         if (EXP != 2)
             stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
         else
-            for (int q = threadIdx.x; q < KPAD(k) * BLOB_P; q += BLOB_T) tile[q] = (u16)((q * 37 + b) % BLOB_S);
+            for (int q = threadIdx.x; q < KPAD(k) * BLOB_P; q += PASS_T) tile[q] = (u16)((q * 37 + b) % BLOB_S);
         const double* self = reinterpret_cast<const double*>(&rec[i]);
         const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
         // outputs go to the caller's index o (device API: ghosts, o >= n_active, are candidates only)
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
             }
             const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
             DensAcc a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            const int nm = KPAD(k) >> 1;
+            const int nm = KPAD(k) / LPP;
             unsigned sl[NB];
             load_slots(sl, tile, 0, half, t);
             for (int m0 = 0; m0 < nm; m0 += NB) {
@@ -283,14 +323,14 @@ __global__ __launch_bounds__(BLOB_T) void blob_density_kernel(int n, int npad, i
 #pragma unroll
                 for (int u = 0; u < NB; ++u) cur[u] = sl[u];
                 if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);    // next batch's slots, behind this one's reads
-                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
                 if (all_staged(cur))
-                    density_batch<true>(a, cur, img, rec, nbr, col0, 2 * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                    density_batch<true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
                 else
-                    density_batch<false>(a, cur, img, rec, nbr, col0, 2 * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                    density_batch<false>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
             }
-            const double s_rho = pair_total(a.rho), s_rd = pair_total(a.rd), s_n = pair_total(a.n);
-            const double gx = pair_total(a.gx), gy = pair_total(a.gy), gz = pair_total(a.gz);
+            const double s_rho = group_total(a.rho), s_rd = group_total(a.rd), s_n = group_total(a.n);
+            const double gx = group_total(a.gx), gy = group_total(a.gy), gz = group_total(a.gz);
             if (EXP == 3) {
                 if (s_rho + gx + s_n + s_rd + gy + gz == 1.2345e-300) rho[o] = 0.0;
             } else if (!half) {
@@ -336,7 +376,7 @@ __device__ __forceinline__ void pi_batch(double& s_pi, double& maxrel, const uns
         const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
         const double r2 = dx * dx + dy * dy + dz * dz;
         const double dot = dvx * dx + dvy * dy + dvz * dz;
-        double w = dot / sqrt(r2 + 0.01 * q0.d);                        // nsc:643
+        double w = dot / sqrt_mid(r2 + 0.01 * q0.d);                    // nsc:643
         w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
         const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
         const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
@@ -345,7 +385,7 @@ __device__ __forceinline__ void pi_batch(double& s_pi, double& maxrel, const uns
     }
 }
 
-__global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_pi_kernel(int n, int npad, int k, int nblk,
                                                          const int* __restrict__ nbr,
                                                          const u16* __restrict__ slot16,
                                                          const int* __restrict__ uniq,
@@ -356,10 +396,10 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
                                                          const RecSelf* __restrict__ selfr, RecBC* bc, double* Pi,
                                                          double* BwOut, u64* ct_bits) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, BLOB_S doubles, slot tile
-    __shared__ u64 sm[BLOB_T / 64];
+    __shared__ u64 sm[PASS_T / 64];
     double* lrho = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lrho + BLOB_S);
-    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
     for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
         const int b = xcd_block(bi, nblk);
@@ -384,7 +424,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
             }
             const double cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
             double s_pi = 0.0, maxrel = 0.0;
-            const int nm = KPAD(k) >> 1;
+            const int nm = KPAD(k) / LPP;
             unsigned sl[NB];
             load_slots(sl, tile, 0, half, t);
             for (int m0 = 0; m0 < nm; m0 += NB) {
@@ -392,14 +432,14 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
 #pragma unroll
                 for (int u = 0; u < NB; ++u) cur[u] = sl[u];
                 if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);
-                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
                 if (all_staged(cur))
-                    pi_batch<true>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, 2 * (size_t)npad, r0, rv, rho_i, cs_i);
+                    pi_batch<true>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, LPP * (size_t)npad, r0, rv, rho_i, cs_i);
                 else
-                    pi_batch<false>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, 2 * (size_t)npad, r0, rv, rho_i, cs_i);
+                    pi_batch<false>(s_pi, maxrel, cur, img, lrho, recb, rho_s, nbr, col0, LPP * (size_t)npad, r0, rv, rho_i, cs_i);
             }
-            s_pi = pair_total(s_pi);
-            maxrel = fmax(maxrel, pair_swap(maxrel));
+            s_pi = group_total(s_pi);
+            maxrel = group_max(maxrel);
             if (!half) {
                 Pi[o] = s_pi;
                 const double bw = fmax(ms_i, 0.0) * s_pi;                       // m Pi [t==0]  nsc:651
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_pi_kernel(int n, int npad, int k,
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 r = sm[0];
-        for (int w = 1; w < BLOB_T / 64; ++w) r = sm[w] < r ? sm[w] : r;
+        for (int w = 1; w < PASS_T / 64; ++w) r = sm[w] < r ? sm[w] : r;
         if (r != 0x7FF0000000000000ull) atomicMin(ct_bits, r);
     }
 }
@@ -459,7 +499,7 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
         const Q4 q0 = q0b[u], qv = qvb[u];
         const double c1 = c1b[u], Bj = qv.d;
         const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double r = sqrt_mid(dx * dx + dy * dy + dz * dz);
         const double r2 = r * r;
         const double qj = q0.d - r2, qi = hi2 - r2;
         const double cb = -6.0 * c1 * (qj * qj);
@@ -472,7 +512,7 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
     }
 }
 
-__global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, int npad, int k, int nblk,
                                                            const int* __restrict__ nbr,
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,
@@ -484,7 +524,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks {x y | z h2 | vx vy | vz Bw}, c1, tile
     double* lc1 = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lc1 + BLOB_S);
-    const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     const double* bcd = reinterpret_cast<const double*>(bc);
     for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
         const int b = xcd_block(bi, nblk);
@@ -509,7 +549,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
             }
             const double hi2 = self0.d, ci = -6.0 * bci.y, Bi = bci.x;
             ViscAcc a{0.0, 0.0, 0.0, 0.0};
-            const int nm = KPAD(k) >> 1;
+            const int nm = KPAD(k) / LPP;
             unsigned sl[NB];
             load_slots(sl, tile, 0, half, t);
             for (int m0 = 0; m0 < nm; m0 += NB) {
@@ -517,13 +557,13 @@ __global__ __launch_bounds__(BLOB_T) void blob_visc_kernel(int n, int npad, int 
 #pragma unroll
                 for (int u = 0; u < NB; ++u) cur[u] = sl[u];
                 if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);
-                const size_t col0 = (size_t)(2 * m0 + half) * npad + p;
+                const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
                 if (all_staged(cur))
-                    visc_batch<true>(a, cur, img, lc1, recb, bc, nbr, col0, 2 * (size_t)npad, r0, rv, hi2, ci, Bi);
+                    visc_batch<true>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
                 else
-                    visc_batch<false>(a, cur, img, lc1, recb, bc, nbr, col0, 2 * (size_t)npad, r0, rv, hi2, ci, Bi);
+                    visc_batch<false>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
             }
-            const double ax = pair_total(a.x), ay = pair_total(a.y), az = pair_total(a.z), heat = pair_total(a.h);
+            const double ax = group_total(a.x), ay = group_total(a.y), az = group_total(a.z), heat = group_total(a.h);
             if (!half) {
                 va[3 * (size_t)o + 0] = -ax; va[3 * (size_t)o + 1] = -ay; va[3 * (size_t)o + 2] = -az;
                 vh[o] = heat * mi / 2.0;                                        // nsc:654
@@ -579,7 +619,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             HIPCHK(hipEventRecord(e0, ctx->stream));
 #define BLOB_EXP_LAUNCH(M)                                                                                           \
-            hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), lds, ctx->stream, (int)n, (int)npad, \
+            hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
                                k, nblk, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,        \
                                nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
             if (mode == 0) BLOB_EXP_LAUNCH(0);
@@ -594,7 +634,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
     }
-    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->rho.as<double>(),
@@ -607,7 +647,7 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_pi_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_pi_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(),
@@ -620,7 +660,7 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(BLOB_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),

@@ -160,6 +160,13 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
     return x * q + (x < r ? x : r) + s;
 }
 
+// Every neighbour sum is kept as this many partial sums over the list positions k mod SPHX_SUM_PARTS,
+// combined as (p0 + p1) [+ (p2 + p3)]: one fixed order for the gather kernels (sphx_sums.hip) and the
+// lanes-per-particle split of the LDS kernels (sphx_blob.hip), so all variants agree bit for bit.
+#ifndef SPHX_SUM_PARTS
+#define SPHX_SUM_PARTS 4
+#endif
+
 // scalar slots in ctx->scal (8-byte units)
 enum {
     SC_CT_BITS = 0,   // u64: min crossing time (bits of a positive double)

@@ -5,10 +5,10 @@
 //   pass 1  rho, rho_dust, n, grad P            needs h_j        nsc:588-619
 //   pass 2  Pi_i = sum_k pi_ik, crossing time   needs rho_j      nsc:639-649, nsc:776-786
 //   pass 3  viscous accel + heat                needs Pi_j       nsc:651-654
-// plus the species pass F[s,i] (nsc:624-627).  Every sum is kept as two partial sums, over the
-// even and the odd list positions (ascending distance), added at the end: a fixed order shared
-// with the two-lanes-per-particle LDS kernels of sphx_blob.hip, so all variants agree bit for
-// bit.  In registers, no atomics: results are bitwise reproducible.
+// plus the species pass F[s,i] (nsc:624-627).  Every sum is kept as SPHX_SUM_PARTS partial sums
+// over the list positions k mod SPHX_SUM_PARTS (ascending distance), added at the end: a fixed
+// order shared with the lanes-per-particle split of the LDS kernels of sphx_blob.hip, so all
+// variants agree bit for bit.  In registers, no atomics: results are bitwise reproducible.
 // Deltas are taken relative to nbr[0][i] (the reference subtracts neighbour 0, nsc:580-581).
 #include "sphx_internal.h"
 // NumPy never fuses a multiply into an add: keep every operation separately rounded so that
@@ -124,6 +124,12 @@ __device__ __forceinline__ Q4 load4(const double* p) {
 // (the passes are bound by gather latency, not arithmetic); the sums still accumulate in list order.
 #define NBATCH 4
 
+// (p0 + p1) [+ (p2 + p3)]: the order the lane groups of sphx_blob.hip combine their partial sums in
+__device__ __forceinline__ double parts_total(const double (&a)[SPHX_SUM_PARTS]) {
+    if (SPHX_SUM_PARTS == 4) return (a[0] + a[1]) + (a[2] + a[3]);
+    return a[0] + a[SPHX_SUM_PARTS - 1];
+}
+
 // ---- pass 1 ---------------------------------------------------------------------------------
 // EXP != 0: timing experiments (extra discarded launch, SPHX_PASS_EXP); 1 = half the record loads
 template <int EXP>
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
     double xr = s0.a, yr = s0.b, zr = s0.c;
     if (j0 >= 0 && j0 != i) { xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
     const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
-    double a_rho[2] = {0.0, 0.0}, a_rd[2] = {0.0, 0.0}, a_n[2] = {0.0, 0.0};
-    double a_gx[2] = {0.0, 0.0}, a_gy[2] = {0.0, 0.0}, a_gz[2] = {0.0, 0.0};
+    double a_rho[SPHX_SUM_PARTS] = {}, a_rd[SPHX_SUM_PARTS] = {}, a_n[SPHX_SUM_PARTS] = {};
+    double a_gx[SPHX_SUM_PARTS] = {}, a_gy[SPHX_SUM_PARTS] = {}, a_gz[SPHX_SUM_PARTS] = {};
     for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
       int jb[NBATCH];
       Q4 q0b[NBATCH], q1b[NBATCH];
@@ -169,16 +175,16 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
         const double qi = hi2 - r2;
         const double ca = ci * (qi * qi);                     // nsc:592
-        a_rho[u & 1] += fmax(ms, 0.0) * W;                    // nsc:605
-        a_rd[u & 1] += fmax(-ms, 0.0) * W;                    // nsc:606
-        a_n[u & 1] += Nw * W;                                 // nsc:607
-        a_gx[u & 1] += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;   // nsc:615
-        a_gy[u & 1] += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
-        a_gz[u & 1] += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
+        a_rho[u & (SPHX_SUM_PARTS - 1)] += fmax(ms, 0.0) * W;                    // nsc:605
+        a_rd[u & (SPHX_SUM_PARTS - 1)] += fmax(-ms, 0.0) * W;                    // nsc:606
+        a_n[u & (SPHX_SUM_PARTS - 1)] += Nw * W;                                 // nsc:607
+        a_gx[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;   // nsc:615
+        a_gy[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
+        a_gz[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
       }
     }
-    const double s_rho = a_rho[0] + a_rho[1], s_rd = a_rd[0] + a_rd[1], s_n = a_n[0] + a_n[1];
-    const double gx = a_gx[0] + a_gx[1], gy = a_gy[0] + a_gy[1], gz = a_gz[0] + a_gz[1];
+    const double s_rho = parts_total(a_rho), s_rd = parts_total(a_rd), s_n = parts_total(a_n);
+    const double gx = parts_total(a_gx), gy = parts_total(a_gy), gz = parts_total(a_gz);
     rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
     rho_s[i] = s_rho;                                         // sorted order: gathered by pass 2
     G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
         const Q4 r0 = load4(rq), rv = load4(rq + 4);                         // x y z h2 | vx vy vz cs
         const RecSelf sf = selfr[i];
         const double rho_i = rho_s[i], cs_i = sf.csi, ms_i = sf.mg, h_i = sf.h;
-        double a_pi[2] = {0.0, 0.0}, maxrel = 0.0;
+        double a_pi[SPHX_SUM_PARTS] = {}, maxrel = 0.0;
         for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
           int jb[NBATCH];
           Q4 q0b[NBATCH], qvb[NBATCH];
@@ -284,11 +290,11 @@ __global__ __launch_bounds__(256) void pass_pi_kernel(int n, int npad, int k, co
             w = (w > 0.0) ? 0.0 : w;                                        // nsc:644
             const double rho_ab = (rho_j + rho_i) / 2.0;                    // nsc:646
             const double c_ab = 0.5 * (qv.d + cs_i);                        // nsc:647
-            a_pi[u & 1] += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;      // nsc:649
+            a_pi[u & (SPHX_SUM_PARTS - 1)] += -0.5 * (c_ab * 2.0 - 3.0 * w) * w / rho_ab;      // nsc:649
             maxrel = fmax(maxrel, dvx * dvx + dvy * dvy + dvz * dvz);       // nsc:780
           }
         }
-        const double s_pi = a_pi[0] + a_pi[1];
+        const double s_pi = parts_total(a_pi);
         Pi[o] = s_pi;
         const double bw = fmax(ms_i, 0.0) * s_pi;                           // m Pi [t==0]  nsc:651
         bc[i].Bw = bw;
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
     const Q4 r0 = load4(rq), rv = load4(rq + 4);
     const double2 bci = *reinterpret_cast<const double2*>(&bc[i]);       // Bw, c1
     const double hi2 = recb[i].h2, ci = -6.0 * bci.y, Bi = bci.x;
-    double a_x[2] = {0.0, 0.0}, a_y[2] = {0.0, 0.0}, a_z[2] = {0.0, 0.0}, a_h[2] = {0.0, 0.0};
+    double a_x[SPHX_SUM_PARTS] = {}, a_y[SPHX_SUM_PARTS] = {}, a_z[SPHX_SUM_PARTS] = {}, a_h[SPHX_SUM_PARTS] = {};
     for (int kk0 = 0; kk0 < k; kk0 += NBATCH) {
       int jb[NBATCH];
       Q4 q0b[NBATCH], qvb[NBATCH];
@@ -367,11 +373,11 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
         const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
         const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
-        a_x[u & 1] += bx; a_y[u & 1] += by; a_z[u & 1] += bz;
-        a_h[u & 1] += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
+        a_x[u & (SPHX_SUM_PARTS - 1)] += bx; a_y[u & (SPHX_SUM_PARTS - 1)] += by; a_z[u & (SPHX_SUM_PARTS - 1)] += bz;
+        a_h[u & (SPHX_SUM_PARTS - 1)] += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
       }
     }
-    const double ax = a_x[0] + a_x[1], ay = a_y[0] + a_y[1], az = a_z[0] + a_z[1], heat = a_h[0] + a_h[1];
+    const double ax = parts_total(a_x), ay = parts_total(a_y), az = parts_total(a_z), heat = parts_total(a_h);
     va[3 * (size_t)o + 0] = -ax; va[3 * (size_t)o + 1] = -ay; va[3 * (size_t)o + 2] = -az;
     vh[o] = heat * m[o] / 2.0;                                              // nsc:654  (m in output order)
 }
