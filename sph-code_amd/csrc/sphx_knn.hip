@@ -453,6 +453,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         else if (mode == 2) hipLaunchKernelGGL((knn_kernel<2, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
         else if (mode == 3) hipLaunchKernelGGL((knn_kernel<3, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
         else if (mode == 4) hipLaunchKernelGGL((knn_kernel<4, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
+        else if (mode == 5 && a.nbr && a.h_sorted) hipLaunchKernelGGL((knn_kernel<5, 1>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);   // lean kernel, one try only (same outputs but for the few short queries; the real launch follows)
         else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, b);
         HIPCHK(hipEventRecord(e1, ctx->stream));
         HIPCHK(hipEventSynchronize(e1));

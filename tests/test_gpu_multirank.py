@@ -88,3 +88,39 @@ def test_ranks_sharing_one_gpu_match_oracle(world, workload, tmp_path):
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
     assert sum(p["stats"][0] for p in parts) > 0
+
+
+@pytest.mark.gpu
+def test_fused_row_kernels_match_tensor_forms():
+    """sphx_dev_pack_rows / sphx_dev_regroup (one launch each) against the tensor-library forms the
+    CPU tests run (DistributedSim._pack / _regroup without a fused backend)."""
+    import torch
+    from sph_code_amd.multigpu import LibBackend, DistributedSim
+    be = LibBackend(0, k=8)
+    dev = be.device
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, nr = 1000, 37
+    pos = torch.rand((n, 3), generator=g, dtype=torch.float64).to(dev)
+    m = torch.rand(n, generator=g, dtype=torch.float64).to(dev)
+    gid = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64).to(dev)
+    idx = torch.randperm(n, generator=g)[:123].to(dev)
+
+    class Plain:                        # no fused helpers: DistributedSim falls back to torch
+        pass
+    shim = DistributedSim.__new__(DistributedSim)
+    shim.backend = Plain()
+    fused = DistributedSim.__new__(DistributedSim)
+    fused.backend = be
+    fields = [pos, m, gid]
+    for ix in (idx, None):
+        a, b = shim._pack(ix, fields), fused._pack(ix, fields)
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    rows = shim._pack(idx[:nr], fields)
+    sel = torch.randperm(n, generator=g)[:800].to(dev)
+    for s_, ns in ((sel, 800), (None, n)):
+        for r_ in (rows, None):
+            a = shim._regroup(s_, ns, r_, fields)
+            b = fused._regroup(s_, ns, r_, fields)
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+    torch.cuda.synchronize()
