@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--neigh", dest="k", type=int, default=40, help="N_NEIGH")
     ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=600_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gravity", default=None, choices=["direct", "tree"],
+                    help="self-gravity in the timed step (off in the BASELINE metric; DESIGN 5.7)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,7 +84,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (libsphx has no CPU path)")
     torch.cuda.set_device(local_rank)
     state = ics.WORKLOADS[args.workload](args.n)
-    sim = Simulation(state, n_neigh=args.k, device=local_rank)
+    sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity)
     sim.step(args.warmup)
     sim.reset_stats()
     torch.cuda.synchronize()
@@ -103,7 +105,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
                                (args.workload, args.n, args.k),
-                   "particles_per_gpu": args.n, "decomposition": "single GPU"},
+                   "particles_per_gpu": args.n, "decomposition": "single GPU",
+                   "gravity": args.gravity or "off"},
         "roofline": {"bound": "hbm", "kernel": "knn_kernel<0,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.n, args.k),
                      "algorithmic_bytes_per_launch": B_SEARCH * args.n,
@@ -113,7 +116,7 @@ def main():
                        "frac_of_hbm_peak": B_STEP_CORE * value / 1e9 / HBM_PEAK_GBS},
         "per_pass_ms": {k_: st[k_] / max(st["steps"], 1) for k_ in
                         ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi", "ms_visc",
-                         "ms_integrate", "ms_total")},
+                         "ms_integrate", "ms_gravity", "ms_total")},
         "search": {"candidates_per_particle_step": st["candidates"] / max(st["steps"], 1) / args.n,
                    "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"],
                    "refresh_steps": st["refresh_steps"], "rebuild_steps": st["rebuild_steps"]},

@@ -158,6 +158,15 @@ int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* points, cons
 int sphx_gravity_direct(sphx_ctx* ctx, int64_t n, const double* mass, const double* points,
                         const double* sizes, double softening, double G, double* accel);
 
+/* The same sum by monopoles of a cell pyramid over a search-style grid (cells sized for k_cells
+ * neighbours, 40 if < 1): level-l cells of 2^l fine cells a side carry (mass, centre of mass); a
+ * particle sums the cells that are children of its parent's +-ws neighbours but not its own +-ws
+ * neighbours, level by level, and the particles of the +-ws level-1 cells directly.  ws = 1..4
+ * (1: ~1 % rms force error, 2: ~0.2 %).  Every monopole is softened like a particle (nsc:385).    */
+int sphx_gravity_tree(sphx_ctx* ctx, int64_t n, const double* mass, const double* points,
+                      const double* sizes, double softening, double G, int ws, int k_cells,
+                      double* accel);
+
 /* AGB dust and gas return per star: calculate_interpolation, sph/config_helper.py:180-211, on the
  * splines of interpolate_amounts (config_helper.py:138-178; RectBivariateSpline kx = ky = 1).
  * Spline o has ntx[o] / nty[o] knots and (ntx[o]-2)*(nty[o]-2) coefficients; tx, ty, coeffs are the
@@ -189,7 +198,9 @@ int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const doub
 /* Self-gravity inside the step loop (drv:448-449,477): mode 1 = direct summation with Plummer
  * softening eps = median(h) of the step (nsc:358), G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2)
  * summed over ALL particles - the sum the reference's tree approximates (sphx_gravity_direct).
- * O(N^2): meant for N up to a few 10^5.  mode 0 switches it off.  Call after sphx_state_upload. */
+ * O(N^2): meant for N up to a few 10^5.  mode 2 = the same sum by cell-pyramid monopoles
+ * (sphx_gravity_tree, ws = 2; SPHX_GRAV_WS overrides), ~1e4 terms per particle.  mode 0 switches it
+ * off.  Call after sphx_state_upload. */
 int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G);
 /* One or more passes of the hot path.  k = N_NEIGH, dist = distance_upper_bound of
  * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
     "sphx_state_set_gravity": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_gravity_direct": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, _D]),
+    "sphx_gravity_tree": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, C.c_int, C.c_int, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),
     "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
     "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),

@@ -225,3 +225,17 @@ def grav_force_direct(mass, points, sizes, G=6.67430e-11):
     dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
     c.check(c.lib.sphx_gravity_direct(c.h, n, dp(m), dp(pts), dp(h), 0.0, float(G), dp(out)))
     return out
+
+
+def grav_force_tree(mass, points, sizes, G=6.67430e-11, ws=2):
+    """The sum of grav_force_direct by monopoles of a cell pyramid (include/sphx.h: sphx_gravity_tree):
+    O(N), ~0.2 % rms force error at ws = 2, ~1 % at ws = 1."""
+    c = context()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    m = np.ascontiguousarray(mass, dtype=np.float64)
+    h = np.ascontiguousarray(sizes, dtype=np.float64)
+    out = np.empty((n, 3))
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+    c.check(c.lib.sphx_gravity_tree(c.h, n, dp(m), dp(pts), dp(h), 0.0, float(G), int(ws), 40, dp(out)))
+    return out

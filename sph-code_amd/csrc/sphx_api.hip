@@ -67,6 +67,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
     if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
     if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess &&
@@ -101,7 +102,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
+                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->grav_pyr, &ctx->grav_cell, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -343,7 +344,9 @@ extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass,
 extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
     if (!ctx) return SPHX_E_ARG;
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_gravity before sphx_state_upload");
-    if (mode != 0 && mode != 1) return sphx_set_err(ctx, SPHX_E_ARG, "gravity mode %d not in {0, 1}", mode);
+    if (mode < 0 || mode > 2) return sphx_set_err(ctx, SPHX_E_ARG, "gravity mode %d not in {0, 1, 2}", mode);
+    if (mode == 2 && ctx->use_verlet)
+        return sphx_set_err(ctx, SPHX_E_STATE, "tree gravity needs the cell grid of every step: not with incremental search");
     ctx->gravity = mode;
     ctx->grav_G = G;
     return SPHX_OK;
@@ -436,12 +439,17 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                 s.mcs.as<double>()));
     HIPCHK(hipEventRecord(ev[6], ctx->stream));
-    if (ctx->gravity == 1) {                     // drv:448-449; softening = median(h), nsc:358
+    if (ctx->gravity) {                          // drv:448-449; softening = median(h), nsc:358
         SPHX_TRY(sphx_ensure(ctx, ctx->grav, (size_t)n * 3 * sizeof(double)));
         double* eps = ctx->scal.as<double>() + SC_GRAV_EPS;
         SPHX_TRY(sphx_median(ctx, n, s.hprev.as<double>(), eps));
-        SPHX_TRY(sphx_gravity_launch(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), 1,
-                                     s.m.as<double>(), eps, 0.0, ctx->grav_G, nullptr, ctx->grav.as<double>()));
+        if (ctx->gravity == 1)
+            SPHX_TRY(sphx_gravity_launch(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), 1,
+                                         s.m.as<double>(), eps, 0.0, ctx->grav_G, nullptr, ctx->grav.as<double>()));
+        else
+            SPHX_TRY(sphx_gravity_tree_launch(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(),
+                                              s.m.as<double>(), ctx->grav_ws, eps, 0.0, ctx->grav_G, nullptr,
+                                              ctx->grav.as<double>()));
     }
     HIPCHK(hipEventRecord(ev[8], ctx->stream));
     SPHX_TRY(sphx_compute_dt(ctx, first, fixed_dt));

@@ -89,6 +89,8 @@ struct sphx_ctx {
     int gravity = 0;              // 1: direct-sum self-gravity each step (sphx_state_set_gravity)
     double grav_G = 0.0;
     DevBuf grav, grav_sort, grav_tmp;   // (n,3) accelerations, sorted h, radix-sort scratch
+    DevBuf grav_pyr, grav_cell;         // cell pyramid (mass, centre of mass), fine cell of each sorted particle
+    int grav_ws = 2;                    // well-separatedness of the tree form (cells)
     // ---- Verlet refresh (sphx_refresh.hip) ----
     DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current
     bool list_valid = false, use_verlet = false;   // opt-in (sphx_set_incremental): pays only for slow drift
@@ -189,6 +191,9 @@ int sphx_median(sphx_ctx* ctx, int64_t n, const double* v, double* out_dev);
 int sphx_gravity_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z, int ps,
                         const double* m, const double* eps_dev, double eps, double G, const int* omap,
                         double* acc);
+int sphx_gravity_tree_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
+                             const double* m, int ws, const double* eps_dev, double eps, double G, const int* omap,
+                             double* acc);
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);

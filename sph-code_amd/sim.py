@@ -35,9 +35,9 @@ class Simulation:
             dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
             dp(f64(state["E_internal"], (n,))), dp(acc)))
         if gravity is not None:
-            if gravity != "direct":
-                raise ValueError("gravity must be None or 'direct'")
-            c.check(c.lib.sphx_state_set_gravity(c.h, 1, float(G)))
+            if gravity not in ("direct", "tree"):
+                raise ValueError("gravity must be None, 'direct' or 'tree'")
+            c.check(c.lib.sphx_state_set_gravity(c.h, 1 if gravity == "direct" else 2, float(G)))
         if with_drag:
             # per-particle mean grain mass / cross-section as nsc.net_impulse forms them (nsc:720-726)
             from . import compat
