@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--neigh", dest="k", type=int, default=40, help="N_NEIGH")
     ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=600_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dt", default="reference", choices=["reference", "cfl"],
+                    help="time step: the reference's rule (drv:222-229; the BASELINE metric) or a fixed Courant-"
+                         "limited step (ics.cfl_dt) under which the dense 1e6 workloads stay stable")
     ap.add_argument("--gravity", default=None, choices=["direct", "tree"],
                     help="self-gravity in the timed step (off in the BASELINE metric; DESIGN 5.7)")
     args = ap.parse_args()
@@ -85,11 +88,12 @@ def main():
     torch.cuda.set_device(local_rank)
     state = ics.WORKLOADS[args.workload](args.n)
     sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity)
-    sim.step(args.warmup)
+    fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0
+    sim.step(args.warmup, fixed_dt=fixed_dt)
     sim.reset_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sim.step(args.steps)                 # returns after the library's stream has drained
+    sim.step(args.steps, fixed_dt=fixed_dt)      # returns after the library's stream has drained
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = sim.stats()
@@ -106,7 +110,7 @@ def main():
         "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
-                   "gravity": args.gravity or "off"},
+                   "gravity": args.gravity or "off", "dt": args.dt},
         "roofline": {"bound": "hbm", "kernel": "knn_kernel<0,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.n, args.k),
                      "algorithmic_bytes_per_launch": B_SEARCH * args.n,
