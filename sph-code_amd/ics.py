@@ -52,20 +52,21 @@ def _unit_vectors(rs, n):
     return u / np.linalg.norm(u, axis=1)[:, None]
 
 
-def uniform_sphere(n, seed=12346, radius=0.625e6 * AU, sigma_v=1000., light=False):
-    """C1."""
+def uniform_sphere(n, seed=12346, radius=0.625e6 * AU, sigma_v=1000., light=False, size_scale=1.0):
+    """C1.  size_scale multiplies every length of the IC (density ~ n / size_scale^3)."""
     rs = np.random.RandomState(seed)
-    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * radius
+    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * (radius * size_scale)
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
     return _finish(pts, vel, mass, T, light=light)
 
 
-def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000., light=False):
+def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000., light=False, size_scale=1.0):
     """C2: radii by inverse CDF of M(<r) ~ int r^2/((r/a)^4+1) dr on the reference's radial grid
     r = sqrt(linspace(0, 25e14, 2001)) AU (imf/lane_emden_modified.py:317-343)."""
     rs = np.random.RandomState(seed)
+    a, rmax = a * size_scale, rmax * size_scale
     r_grid = np.sqrt(np.linspace(0., (rmax / AU) ** 2, 2001)) * AU
     dens = 1. / ((r_grid / a) ** 4 + 1.)
     shell = 0.5 * (dens[1:] * r_grid[1:] ** 2 + dens[:-1] * r_grid[:-1] ** 2) * np.diff(r_grid)
@@ -80,11 +81,12 @@ def polytrope_sphere(n, seed=12347, a=2e7 * AU, rmax=5e7 * AU, sigma_v=1000., li
     return _finish(pts, vel, mass, T, light=light)
 
 
-def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.28 * SOLAR, light=False):
+def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.28 * SOLAR, light=False,
+                 size_scale=1.0):
     """C3: cold uniform gas; the innermost `kick_mass` of gas receives 73.6 % of `energy` as a
     radial kick and 26.4 % as heat."""
     rs = np.random.RandomState(seed)
-    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * radius
+    pts = _unit_vectors(rs, n) * (rs.rand(n) ** (1. / 3.))[:, None] * (radius * size_scale)
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * 100.
@@ -105,14 +107,27 @@ def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.
     return st
 
 
-def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000., light=False):
+def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000., light=False, size_scale=1.0):
     """C4: the reference's own IC (sph/code_running.py:62,132)."""
     rs = np.random.RandomState(seed)
-    pts = (rs.rand(n, 3) - 0.5) * side
+    pts = (rs.rand(n, 3) - 0.5) * (side * size_scale)
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
     return _finish(pts, vel, mass, T, light=light)
+
+
+def bench_size_scale(n_total):
+    """Length scale of the benchmark cloud.  1 at the BASELINE size (1e6 particles: the reference's IC as
+    it is).  Beyond it the cloud is enlarged by (N/1e6)^(1/3) x 16: the reference's scheme is unstable
+    (unclipped neighbour gradient, nsc:591; first dt up to 2 dt_0, drv:226) and the more particles a cloud
+    has the worse its worst local configuration - at constant density a 2e6..8e6-particle polytrope
+    diverges within 3 steps (max|v| 1e22 m/s), diluted x4 the 8e6 one still does after 12; at x16 the
+    fastest particle drifts ~0.3 h per step, as in the 1e6 case, and 4e6 / 8e6 particles stay sane for
+    30+ steps (measured on one MI355X).  The work per particle-step does not depend on the scale."""
+    if n_total <= 1_000_000:
+        return 1.0
+    return 16.0 * (n_total / 1e6) ** (1. / 3.)
 
 
 def cfl_dt(state, k=40, courant=0.25):

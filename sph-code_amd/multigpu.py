@@ -641,7 +641,8 @@ def bench_main(args, rank, local_rank, world):
         dist.init_process_group(backend, rank=rank, world_size=world)
         comm_dev = torch.device("cpu")
     n_global = args.n * world                       # weak scaling: fixed particles per GPU
-    state = ics.WORKLOADS[args.workload](n_global, light=True)
+    scale = ics.bench_size_scale(n_global)          # keeps the reference's scheme in its stable regime
+    state = ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale)
     mine, lo, hi = decompose_state(state, world, rank)
     del state
     be = LibBackend(dev_index, k=args.k)
@@ -664,6 +665,10 @@ def bench_main(args, rank, local_rank, world):
                         float(sim.ex.bytes_sent) / max(args.steps, 1), float(sim.stats["redo"])],
                        dtype=torch.float64, device=comm_dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    v2 = (sim.s["vel"] ** 2).sum(dim=1)
+    chk = torch.stack([torch.sqrt(v2.max()) if v2.numel() else v2.new_zeros(()),
+                       (~torch.isfinite(sim.s["pos"])).sum().to(torch.float64)]).to(comm_dev)
+    dist.all_reduce(chk, op=dist.ReduceOp.MAX)
     if rank == 0:
         t = float(tmax[0])
         total = float(cnt[0])
@@ -677,7 +682,9 @@ def bench_main(args, rank, local_rank, world):
                                    % (args.workload, int(total), args.n, args.k),
                        "particles_per_gpu": args.n,
                        "decomposition": "recursive coordinate bisection, %d regions, 4-phase p2p halo" % world,
-                       "backend": backend},
+                       "backend": backend, "cloud_size_scale": scale},
+            "state_check": {"finite": float(chk[1]) == 0.0, "max_speed_m_s": float(chk[0]),
+                            "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
                      "search_redos": float(cnt[3])},
             "step_model": {"algorithmic_bytes_per_particle_step": 1248,
