@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--dt", default="reference", choices=["reference", "cfl"],
                     help="time step: the reference's rule (drv:222-229; the BASELINE metric) or a fixed Courant-"
                          "limited step (ics.cfl_dt) under which the dense 1e6 workloads stay stable")
+    ap.add_argument("--clip-grad", action="store_true",
+                    help="physics option sphx_set_clip_grad (not the reference's hydro_update arithmetic; same cost)")
+    ap.add_argument("--natural-size", action="store_true",
+                    help="do not enlarge the cloud beyond 1e6 particles (ics.bench_size_scale)")
     ap.add_argument("--gravity", default=None, choices=["direct", "tree"],
                     help="self-gravity in the timed step (off in the BASELINE metric; DESIGN 5.7)")
     args = ap.parse_args()
@@ -86,9 +90,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsphx has no CPU path)")
     torch.cuda.set_device(local_rank)
-    scale = ics.bench_size_scale(args.n)           # 1 at the BASELINE size; see ics.bench_size_scale
+    # 1 at the BASELINE size; see ics.bench_size_scale
+    scale = (args.n / 1e6) ** (1. / 3.) if (args.natural_size and args.n > 1e6) else ics.bench_size_scale(args.n)
     state = ics.WORKLOADS[args.workload](args.n, size_scale=scale)
-    sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity)
+    sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad)
     fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0
     sim.step(args.warmup, fixed_dt=fixed_dt)
     sim.reset_stats()
@@ -114,7 +119,8 @@ def main():
         "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
-                   "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale},
+                   "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale,
+                   "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)"},
         # the reference's scheme can diverge: evidence that the timed window was a sane flow
         "state_check": {"finite": sane, "max_speed_m_s": vmax,
                         "max_drift_per_step_in_mean_h": vmax * float(final["dt"]) / float(final["sizes"].mean())},

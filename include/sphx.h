@@ -195,6 +195,12 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
  * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
  * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
 int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
+/* Physics option, off by default.  hydro_update's neighbour-side kernel gradient
+ * -6 C h_j^-9 (h_j^2 - r^2)^2 is not clipped for r > h_j (nsc:591) - reproduced for parity, but it grows as
+ * r^4 and makes long runs of the vectorised form diverge; the reference's own time loop uses the loop forms,
+ * which clip it (nsc:689).  on != 0 clips it (0 for h_j^2 - r^2 <= 0) in sphx_hydro_update, sphx_step and
+ * the sphx_dev_* passes of this context.                                                          */
+int sphx_set_clip_grad(sphx_ctx* ctx, int on);
 /* Self-gravity inside the step loop (drv:448-449,477): mode 1 = direct summation with Plummer
  * softening eps = median(h) of the step (nsc:358), G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2)
  * summed over ALL particles - the sum the reference's tree approximates (sphx_gravity_direct).

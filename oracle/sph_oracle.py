@@ -83,7 +83,7 @@ def neighbors_bruteforce(points, dist, n_neigh):
 # ==========================================================================================
 # vectorised SPH sums                                                        nsc:556-671
 # ==========================================================================================
-def _pair_geometry(nb, pts, vel, h, lo, hi):
+def _pair_geometry(nb, pts, vel, h, lo, hi, clip_grad=False):
     """Pair geometry for rows lo:hi.  Deltas are relative to nb[i,0] (nsc:580-581)."""
     n = len(pts)
     nbc = nb[lo:hi]
@@ -101,6 +101,8 @@ def _pair_geometry(nb, pts, vel, h, lo, hi):
         W = W6_C / hj ** 9 * qj ** 3                  # nsc:588
         W = np.where(W < 0, 0., W)                    # nsc:589
         cb = -6. * W6_C / hj ** 9 * qj ** 2           # nsc:591 (not clipped)
+        if clip_grad:                                 # physics option: as the loop forms, nsc:689
+            cb = np.where(qj > 0, cb, 0.)
         qi = hi_ * hi_ - r * r
         ca = -6. * W6_C / hi_ ** 9 * qi ** 2          # nsc:592
     W = np.where(valid, W, 0.)
@@ -110,7 +112,8 @@ def _pair_geometry(nb, pts, vel, h, lo, hi):
 
 
 def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array, gamma_array,
-                 velocities, chunk=32768, return_intermediates=False, rho_in=None, Bj_in=None):
+                 velocities, chunk=32768, return_intermediates=False, rho_in=None, Bj_in=None,
+                 clip_grad=False):
     """Restatement of nsc:556-671 with the axis repair of SURVEY F5 (Pi_i = sum_k pi_ik).
 
     Returns (hydro_accel (N,3), visc_accel (N,3), visc_heat (N,), density (N,),
@@ -145,7 +148,7 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
     inter = {}
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi)
+        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi, clip_grad)
         mg = np.where(valid, (m * gas)[j], 0.)
         rho[lo:hi] = np.sum(mg * W, axis=1)                                  # nsc:605
         rho_d[lo:hi] = np.sum(np.where(valid, (m * dust)[j], 0.) * W, axis=1)  # nsc:606
@@ -170,7 +173,7 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
     Pi = np.zeros(n)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi)
+        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi, clip_grad)
         with np.errstate(all="ignore"):
             w = np.sum(dv * dx, axis=2) / np.sqrt(r2 + 0.01 * hj ** 2)       # nsc:643
             w = np.where(w > 0., 0., w)                                      # nsc:644
@@ -191,7 +194,7 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
         Bj = np.asarray(Bj_in, dtype=np.float64)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi)
+        j, valid, dx, dv, r2, hj, W, cb, ca = _pair_geometry(nb, pts, vel, h, lo, hi, clip_grad)
         B = ((np.where(valid, Bj[j], 0.) * cb)[..., None] * dx
              + (Bj_own[lo:hi][:, None] * ca)[..., None] * dx) / 2.
         visc_accel[lo:hi] = -np.sum(B, axis=1)                                # nsc:651-652
@@ -414,7 +417,7 @@ def gravity_direct(points, mass, softening, G=G_NEWTON, chunk=512):
 
 
 def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, workers=1,
-         fixed_dt=0.0, with_drag=False, with_gravity=False, grav_G=None):
+         fixed_dt=0.0, with_drag=False, with_gravity=False, grav_G=None, clip_grad=False):
     """One pass of the hot path: search -> dt -> sums -> leapfrog update.
 
     state: dict with points, velocities, mass, particle_type, f_un, T, mu_array, gamma_array,
@@ -430,7 +433,7 @@ def step(state, n_neigh=40, dist=np.inf, eps=0.0, first=False, grav_accel=None, 
     if fu is None:                       # light ICs do not carry the (N,15) composition
         fu = np.ones((len(p), 1))
     ha, va, vh, rho, nden, F, rho_d = hydro_update(nb, p, s["mass"], h, fu, s["particle_type"],
-                                                   s["T"], s["mu_array"], s["gamma_array"], v)
+                                                   s["T"], s["mu_array"], s["gamma_array"], v, clip_grad=clip_grad)
     if with_gravity:                                                           # drv:448-449, nsc:358
         grav_accel = gravity_direct(p, s["mass"], np.median(h), G=G_NEWTON if grav_G is None else grav_G)
     drag = None

@@ -110,9 +110,11 @@ def neighbors(points, dist, N_NEIGH, eps=0.1):
     return idx, None, dd, nontriv, h
 
 
-def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array, gamma_array, velocities):
+def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array, gamma_array, velocities,
+                 clip_grad=False):
     """nsc:556-671 -> (hydro_accel (N,3), visc_accel (N,3), visc_heat (N,), density_calc (N,),
-    num_density_calc (N,), f_un_neighbor (S,N), dust_density_calc (N,))."""
+    num_density_calc (N,), f_un_neighbor (S,N), dust_density_calc (N,)).  clip_grad=True: the physics option
+    of include/sphx.h sphx_set_clip_grad (not the reference's arithmetic)."""
     nb, n, K = _nk(neighbor)
     pts = f64(points, (n, 3)); vel = f64(velocities, (n, 3))
     m = f64(mass, (n,)); h = f64(sizes, (n,)); pt = f64(particle_type, (n,))
@@ -124,9 +126,13 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
     ha = np.empty((n, 3)); va = np.empty((n, 3)); vh = np.empty(n)
     rho = np.empty(n); nden = np.empty(n); F = np.empty((S, n)); rhod = np.empty(n)
     c = context()
-    c.check(c.lib.sphx_hydro_update(c.h, n, K, S, ip(nb), dp(pts), dp(m), dp(h), dp(fu), dp(pt), dp(Tt),
-                                    dp(mu), dp(gam), dp(vel), 0, dp(ha), dp(va), dp(vh), dp(rho),
-                                    dp(nden), dp(F), dp(rhod)))
+    c.check(c.lib.sphx_set_clip_grad(c.h, 1 if clip_grad else 0))
+    try:
+        c.check(c.lib.sphx_hydro_update(c.h, n, K, S, ip(nb), dp(pts), dp(m), dp(h), dp(fu), dp(pt), dp(Tt),
+                                        dp(mu), dp(gam), dp(vel), 0, dp(ha), dp(va), dp(vh), dp(rho),
+                                        dp(nden), dp(F), dp(rhod)))
+    finally:
+        c.lib.sphx_set_clip_grad(c.h, 0)
     return ha, va, vh, rho, nden, F, rhod
 
 

@@ -341,6 +341,12 @@ extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass,
     return SPHX_OK;
 }
 
+extern "C" int sphx_set_clip_grad(sphx_ctx* ctx, int on) {
+    if (!ctx) return SPHX_E_ARG;
+    ctx->clip_grad = on ? 1 : 0;
+    return SPHX_OK;
+}
+
 extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
     if (!ctx) return SPHX_E_ARG;
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_gravity before sphx_state_upload");

@@ -225,7 +225,7 @@ __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, con
 // each of them (the usual case): straight-line LDS reads and arithmetic, nothing to branch on.
 // Otherwise a position may be empty (skipped) or unstaged (fetched through the int32 list).
 struct DensAcc { double rho, rd, n, gx, gy, gz; };
-template <bool FAST>
+template <bool FAST, bool CLIP>
 __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[NB], const double2* img,
                                               const RecA* __restrict__ rec, const int* __restrict__ nbr,
                                               size_t col0, size_t colstep, double xr, double yr, double zr,
@@ -251,7 +251,7 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
         const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
         double W = c1 * (qj * qj * qj);                       // nsc:588
         W = (W < 0.0) ? 0.0 : W;                              // nsc:589
-        const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
+        const double cb = (CLIP && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);   // nsc:591 (not clipped; CLIP: nsc:689)
         const double qi = hi2 - r2;
         const double ca = ci * (qi * qi);                     // nsc:592
         a.rho += fmax(ms, 0.0) * W;                           // nsc:605
@@ -279,7 +279,7 @@ __device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
 // EXP != 0: timing experiments on an extra, discarded launch (SPHX_BLOB_EXP): 1 = staging only,
 // 2 = neighbour loop only (image not filled), 3 = both but no global stores at the end.
 template <int EXP>
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int n, int npad, int k, int nblk, int clip,
                                                               const int* __restrict__ nbr,
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
@@ -324,10 +324,11 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int 
                 for (int u = 0; u < NB; ++u) cur[u] = sl[u];
                 if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);    // next batch's slots, behind this one's reads
                 const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
-                if (all_staged(cur))
-                    density_batch<true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
-                else
-                    density_batch<false>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                const bool fast = all_staged(cur);
+                if (fast && !clip) density_batch<true, false>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                else if (fast) density_batch<true, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                else if (!clip) density_batch<false, false>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
+                else density_batch<false, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai);
             }
             const double s_rho = group_total(a.rho), s_rd = group_total(a.rd), s_n = group_total(a.n);
             const double gx = group_total(a.gx), gy = group_total(a.gy), gz = group_total(a.gz);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_pi_kernel(int n, in
 
 // ---- pass 3: viscous acceleration + heat      nsc:651-654 --------------------------------------
 struct ViscAcc { double x, y, z, h; };
-template <bool FAST>
+template <bool FAST, bool CLIP>
 __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB], const double2* img,
                                            const double* lc1, const RecB* __restrict__ recb,
                                            const RecBC* __restrict__ bc, const int* __restrict__ nbr, size_t col0,
@@ -502,7 +503,7 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
         const double r = sqrt_mid(dx * dx + dy * dy + dz * dz);
         const double r2 = r * r;
         const double qj = q0.d - r2, qi = hi2 - r2;
-        const double cb = -6.0 * c1 * (qj * qj);
+        const double cb = (CLIP && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);
         const double ca = ci * (qi * qi);
         const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
         const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
@@ -512,7 +513,7 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
     }
 }
 
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, int npad, int k, int nblk, int clip,
                                                            const int* __restrict__ nbr,
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,
@@ -558,10 +559,11 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, 
                 for (int u = 0; u < NB; ++u) cur[u] = sl[u];
                 if (m0 + NB < nm) load_slots(sl, tile, m0 + NB, half, t);
                 const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
-                if (all_staged(cur))
-                    visc_batch<true>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
-                else
-                    visc_batch<false>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
+                const bool fast = all_staged(cur);
+                if (fast && !clip) visc_batch<true, false>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
+                else if (fast) visc_batch<true, true>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
+                else if (!clip) visc_batch<false, false>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
+                else visc_batch<false, true>(a, cur, img, lc1, recb, bc, nbr, col0, LPP * (size_t)npad, r0, rv, hi2, ci, Bi);
             }
             const double ax = group_total(a.x), ay = group_total(a.y), az = group_total(a.z), heat = group_total(a.h);
             if (!half) {
@@ -620,7 +622,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             HIPCHK(hipEventRecord(e0, ctx->stream));
 #define BLOB_EXP_LAUNCH(M)                                                                                           \
             hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
-                               k, nblk, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,        \
+                               k, nblk, ctx->clip_grad, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, \
                                nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
             if (mode == 0) BLOB_EXP_LAUNCH(0);
             else if (mode == 1) BLOB_EXP_LAUNCH(1);
@@ -634,7 +636,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
     }
-    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->rho.as<double>(),
@@ -660,7 +662,7 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),

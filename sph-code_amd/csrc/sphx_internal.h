@@ -86,6 +86,7 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
+    int clip_grad = 0;            // physics option: neighbour-side gradient clipped beyond h_j (sphx_set_clip_grad)
     int gravity = 0;              // 1: direct-sum self-gravity each step (sphx_state_set_gravity)
     double grav_G = 0.0;
     DevBuf grav, grav_sort, grav_tmp;   // (n,3) accelerations, sorted h, radix-sort scratch

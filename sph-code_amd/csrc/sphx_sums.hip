@@ -133,7 +133,8 @@ __device__ __forceinline__ double parts_total(const double (&a)[SPHX_SUM_PARTS])
 // ---- pass 1 ---------------------------------------------------------------------------------
 // EXP != 0: timing experiments (extra discarded launch, SPHX_PASS_EXP); 1 = half the record loads
 template <int EXP>
-__global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+__global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int k, int clip,
+                                                           const int* __restrict__ nbr,
                                                            const RecA* __restrict__ rec, double* rho_s,
                                                            const int* __restrict__ qorder, OutMap om, double* rho,
                                                            double* rhod, double* nden, double* G,
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         const double c1 = q1.a, ms = q1.b, Aj = q1.c, Nw = q1.d;
         double W = c1 * (qj * qj * qj);                       // nsc:588
         W = (W < 0.0) ? 0.0 : W;                              // nsc:589
-        const double cb = -6.0 * c1 * (qj * qj);              // nsc:591 (not clipped)
+        const double cb = (clip && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);   // nsc:591 (not clipped; clip: nsc:689)
         const double qi = hi2 - r2;
         const double ca = ci * (qi * qi);                     // nsc:592
         a_rho[u & (SPHX_SUM_PARTS - 1)] += fmax(ms, 0.0) * W;                    // nsc:605
@@ -209,11 +210,11 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
         HIPCHK(hipEventRecord(e0, ctx->stream));
         if (mode == 1)
             hipLaunchKernelGGL(pass_density_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
+                               (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
                                ctx->qorder, OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
         else
             hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
+                               (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), d,
                                ctx->qorder, OutMap{nullptr, (int)n}, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n);
         HIPCHK(hipEventRecord(e1, ctx->stream));
         HIPCHK(hipEventSynchronize(e1));
@@ -223,7 +224,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
+                       (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->qorder, OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
                        ctx->G.as<double>(), ctx->ha.as<double>());
@@ -327,7 +328,8 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
 }
 
 // ---- pass 3 ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+__global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, int clip,
+                                                        const int* __restrict__ nbr,
                                                         const RecB* __restrict__ recb,
                                                         const RecBC* __restrict__ bc,
                                                         const int* __restrict__ qorder, OutMap om,
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const double r2 = r * r;
         const double qj = q0.d - r2, qi = hi2 - r2;
-        const double cb = -6.0 * c1 * (qj * qj);
+        const double cb = (clip && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);
         const double ca = ci * (qi * qi);
         const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
         const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
@@ -387,7 +389,7 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(sphx_ensure(ctx, ctx->vh, (size_t)n * sizeof(double)));
     if (ctx->qorder && ctx->blob_lists) return sphx_blob_visc(ctx, n, k, m);
     hipLaunchKernelGGL(pass_visc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
+                       (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), ctx->qorder,
                        OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n}, m,
                        ctx->va.as<double>(), ctx->vh.as<double>());

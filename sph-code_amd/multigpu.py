@@ -150,9 +150,10 @@ class Exchanger:
 # compute backend on the GPU: libsphx sphx_dev_* (include/sphx.h)
 # ==============================================================================================
 class LibBackend:
-    def __init__(self, device_index, k=40, dist_bound=0.0):
+    def __init__(self, device_index, k=40, dist_bound=0.0, clip_grad=False):
         from . import _lib
         self.ctx = _lib.Context(device_index)
+        self.ctx.check(self.ctx.lib.sphx_set_clip_grad(self.ctx.h, 1 if clip_grad else 0))
         self.lib = self.ctx.lib
         self.k = k
         self.dist_bound = dist_bound
@@ -642,10 +643,12 @@ def bench_main(args, rank, local_rank, world):
         comm_dev = torch.device("cpu")
     n_global = args.n * world                       # weak scaling: fixed particles per GPU
     scale = ics.bench_size_scale(n_global)          # keeps the reference's scheme in its stable regime
+    if getattr(args, "natural_size", False) and n_global > 1e6:
+        scale = (n_global / 1e6) ** (1. / 3.)
     state = ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale)
     mine, lo, hi = decompose_state(state, world, rank)
     del state
-    be = LibBackend(dev_index, k=args.k)
+    be = LibBackend(dev_index, k=args.k, clip_grad=getattr(args, "clip_grad", False))
     sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev)
     for _ in range(args.warmup):
         sim.step()

@@ -15,7 +15,7 @@ from ._lib import dp, f64
 
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
-                 incremental=False, with_drag=False, gravity=None, G=6.67430e-11):
+                 incremental=False, with_drag=False, gravity=None, G=6.67430e-11, clip_grad=False):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -34,6 +34,7 @@ class Simulation:
             dp(f64(state["particle_type"], (n,))), dp(fu), dp(f64(state["T"], (n,))),
             dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
             dp(f64(state["E_internal"], (n,))), dp(acc)))
+        c.check(c.lib.sphx_set_clip_grad(c.h, 1 if clip_grad else 0))
         if gravity is not None:
             if gravity not in ("direct", "tree"):
                 raise ValueError("gravity must be None, 'direct' or 'tree'")

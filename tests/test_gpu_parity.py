@@ -247,6 +247,12 @@ def test_step_trajectory_vs_oracle(workload):
         ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0), fixed_dt=fixed_dt)
         got = sim.download()
         assert got["dt"] == pytest.approx(ref["dt"], rel=1e-12), "dt at step %d" % it
+        if it == 2:
+            # three steps in, before the reference's scheme has flung anything far (it diverges on these
+            # clouds from step 4-5 on): every particle individually, against the cloud's size
+            R0 = np.max(np.abs(s0["points"]))
+            assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-12 * R0
+            assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-10 * np.max(np.abs(ref["velocities"]))
     L = np.max(np.abs(ref["points"]))
     V = np.max(np.abs(ref["velocities"]))
     assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * L
@@ -255,6 +261,42 @@ def test_step_trajectory_vs_oracle(workload):
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-9)
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
     np.testing.assert_allclose(got["T"], ref["T"], rtol=1e-9)
+
+
+def test_clip_grad_option_vs_oracle_and_stability(nsc):
+    """Physics option (sphx_set_clip_grad): the neighbour-side gradient clipped beyond h_j, as
+    the reference's loop forms do (nsc:689).  hydro_update with it against the oracle on the golden inputs;
+    then the C1 sphere, which the unclipped form blows apart within 5 steps, stays a quiet cloud for 12 and
+    tracks the oracle particle by particle."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    from conftest import load_golden
+    args = hydro_args(load_golden("sphere_dust_n2048_k40"))
+    out = nsc.hydro_update(*args, clip_grad=True)
+    ref = orc.hydro_update(*args, clip_grad=True)
+    plain = nsc.hydro_update(*args)
+    for i in (3, 4, 6):
+        np.testing.assert_allclose(out[i], ref[i], rtol=RTOL_POS)
+    for i in (0, 1, 2):
+        _signed_close(out[i], ref[i], "clip output %d" % i)
+    assert np.max(np.abs(out[0] - plain[0])) > 1e-3 * np.max(np.abs(plain[0]))      # the option does something
+    again = nsc.hydro_update(*args)                                                  # and does not stick
+    assert all(np.array_equal(a, b) for a, b in zip(again, plain))
+    n, K, nsteps = 4096, 40, 12
+    s0 = ics.uniform_sphere(n)
+    sim = Simulation(s0, n_neigh=K, clip_grad=True)
+    ref = dict(s0)
+    for it in range(nsteps):
+        sim.step(1)
+        ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0), clip_grad=True)
+    got = sim.download()
+    R0 = np.max(np.abs(s0["points"]))
+    assert np.max(np.abs(ref["velocities"])) < 1e5 and np.max(np.abs(ref["points"])) < 5 * R0     # a quiet cloud
+    assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-10 * R0
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-9)
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
 
 
 def test_step_with_drag_vs_oracle():
