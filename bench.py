@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--dt", default="reference", choices=["reference", "cfl"],
                     help="time step: the reference's rule (drv:222-229; the BASELINE metric) or a fixed Courant-"
                          "limited step (ics.cfl_dt) under which the dense 1e6 workloads stay stable")
+    ap.add_argument("--forms", default="hydro_update", choices=["hydro_update", "loop"],
+                    help="sums of the step: nsc.hydro_update's (the BASELINE metric) or the loop forms of the reference's "
+                         "time loop (sphx_state_set_loop_forms; d set so that h(m) ~ the median kNN radius)")
     ap.add_argument("--clip-grad", action="store_true",
                     help="physics option sphx_set_clip_grad (not the reference's hydro_update arithmetic; same cost)")
     ap.add_argument("--natural-size", action="store_true",
@@ -93,7 +96,14 @@ def main():
     # 1 at the BASELINE size; see ics.bench_size_scale
     scale = (args.n / 1e6) ** (1. / 3.) if (args.natural_size and args.n > 1e6) else ics.bench_size_scale(args.n)
     state = ics.WORKLOADS[args.workload](args.n, size_scale=scale)
-    sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad)
+    d_loop = None
+    if args.forms == "loop":
+        from scipy.spatial import cKDTree
+        sub = state["points"][:: max(1, args.n // 200000)]
+        hs = cKDTree(sub).query(sub, k=args.k)[0][:, -1] * (len(sub) / args.n) ** (1. / 3.)
+        d_loop = float(np.median(hs) / np.median((state["mass"] / 10 ** 1.5 / 1.989e30) ** (1. / 3.)))
+    sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad,
+                     forms=args.forms, d=d_loop)
     fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0
     sim.step(args.warmup, fixed_dt=fixed_dt)
     sim.reset_stats()
@@ -120,6 +130,7 @@ def main():
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
                    "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale,
+                   "forms": args.forms,
                    "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)"},
         # the reference's scheme can diverge: evidence that the timed window was a sane flow
         "state_check": {"finite": sane, "max_speed_m_s": vmax,

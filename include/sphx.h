@@ -195,6 +195,14 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
  * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
  * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
 int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
+/* Step mode "loop forms": on != 0 makes sphx_step evaluate, on its own neighbour list, exactly what the
+ * reference's time loop evaluates (drv:451-458): density, dust_density, num_dens, del_pressure,
+ * artificial_viscosity and crossing_time in their loop forms (nsc:673-816; smoothing length
+ * h(m) = (m/m_0)^(1/3) d with the driver's global d, clipped gradients, physical sign), then
+ * pressure_accel = delp / rho [gas], visc_accel = av[0] (+ drag), limiter, leapfrog, E += av[1] dt
+ * (drv:460-491).  The default (on == 0) uses the vectorised sums of nsc.hydro_update instead.
+ * Call after sphx_state_upload; `dist` of sphx_step is the search bound the driver passes (drv:437). */
+int sphx_state_set_loop_forms(sphx_ctx* ctx, int on, double d);
 /* Physics option, off by default.  hydro_update's neighbour-side kernel gradient
  * -6 C h_j^-9 (h_j^2 - r^2)^2 is not clipped for r > h_j (nsc:591) - reproduced for parity, but it grows as
  * r^4 and makes long runs of the vectorised form diverge; the reference's own time loop uses the loop forms,

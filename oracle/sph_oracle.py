@@ -397,6 +397,40 @@ def integrate(p, v, old, E_internal, mass, mu_array, gamma_array, particle_type,
     return p, v, total, E, T
 
 
+def step_loop(state, d, n_neigh=40, dist=np.inf, eps=0.0, first=False, fixed_dt=0.0, with_drag=False,
+              grav_accel=None, workers=1):
+    """One pass of the reference's time loop as it is written (drv:222-238, 437, 451-491): the LOOP
+    forms on the step's neighbour list, global d.  Integrator restated from text (driver not runnable)."""
+    s = dict(state)
+    p, v = clamp_state(s["points"], s["velocities"])
+    m, pt = s["mass"], s["particle_type"]
+    nb, _, _, _, h = neighbors(p, dist, n_neigh, eps, workers=workers)               # drv:437
+    ct = crossing_time(nb, v, h, pt)                                                  # drv:222
+    dt = fixed_dt if fixed_dt > 0 else timestep(ct, first)
+    rho = density(p, m, pt, nb, d)                                                    # drv:451
+    rho_d = dust_density(p, m, nb, pt, h)                                             # drv:452
+    nden = num_dens(m, p, s["mu_array"], nb, d)                                       # drv:453
+    delp = del_pressure(p, m, pt, nb, s["E_internal"], s["gamma_array"], d)           # drv:456
+    av = artificial_viscosity(nb, p, pt, h, m, rho, v, s["T"], s["gamma_array"], s["mu_array"], d)   # drv:458
+    gas = (np.asarray(pt) == 0.)[:, None]
+    with np.errstate(all="ignore"):
+        pressure_accel = np.nan_to_num(delp / rho[:, None] * gas)                     # drv:460
+        visc = av[0]
+        if with_drag:                                                                 # drv:455,462-463,473
+            onto, react = net_impulse(p, m, h, v, pt, nb, s["f_un"])
+            visc = np.nan_to_num(onto * (rho_d / rho)[:, None] * gas) + np.nan_to_num(react) + av[0]
+        vn = np.sqrt(np.sum(v ** 2, axis=1)); an = np.sqrt(np.sum(visc ** 2, axis=1))
+        visc = np.where(((vn - an * dt) < 0)[:, None], -v / dt, visc)                 # drv:475
+        total = grav_accel + pressure_accel + visc if grav_accel is not None else pressure_accel + visc
+        pn = p + (total * dt ** 2) / 2. + v * dt                                      # drv:481
+        vnew = v + (total + s["total_accel"]) / 2. * dt                               # drv:482-486
+        E = np.nan_to_num(s["E_internal"]) + np.nan_to_num(av[1] * dt)                # drv:490
+        T = np.nan_to_num(E * (s["mu_array"] * M_H) / (s["gamma_array"] * m * K_B))   # drv:491
+    s.update(points=pn, velocities=vnew, total_accel=total, E_internal=E, T=T, dt=dt, sizes=h, densities=rho,
+             num_densities=nden, dust_densities=rho_d, neighbor=nb)
+    return s
+
+
 G_NEWTON = 6.67430e-11        # scipy.constants.G (nsc:21)
 
 

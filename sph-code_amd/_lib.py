@@ -53,6 +53,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_int32), C.c_double, C.c_int, _D, _D, C.c_double, _D, _D]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
+    "sphx_state_set_loop_forms": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_set_clip_grad": (C.c_int, [_P, C.c_int]),
     "sphx_state_set_gravity": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_gravity_direct": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, _D]),

@@ -317,6 +317,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->has_state = true;
     ctx->drag = false;
     ctx->gravity = 0;
+    ctx->loop_forms = 0;
     ctx->list_valid = false;
     ctx->clip_valid = false;
     ctx->h_clip = 0.0;
@@ -338,6 +339,16 @@ extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass,
     HIPCHK(hipMemcpyAsync(ctx->st.mcs.p, mean_cross, nb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->drag = true;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_state_set_loop_forms(sphx_ctx* ctx, int on, double d) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_loop_forms before sphx_state_upload");
+    if (on && !(d > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "the loop forms need the driver's global d > 0 (drv:68)");
+    if (on && ctx->use_verlet) return sphx_set_err(ctx, SPHX_E_STATE, "loop-form steps are not combined with incremental search");
+    ctx->loop_forms = on ? 1 : 0;
+    ctx->loop_d = d;
     return SPHX_OK;
 }
 
@@ -402,7 +413,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             SPHX_TRY(sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint));
         }
         SPHX_TRY(sphx_permute_state(ctx, n));
-        if (ctx->use_blob && !ctx->use_verlet) SPHX_TRY(sphx_build_blob_order(ctx, n));
+        if (ctx->use_blob && !ctx->use_verlet && !ctx->loop_forms) SPHX_TRY(sphx_build_blob_order(ctx, n));
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         StateArrays& r = ctx->st;
         KnnOut o;
@@ -431,6 +442,21 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
+    if (ctx->loop_forms) {
+        // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
+        if (ctx->drag)
+            SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
+                               s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
+                               s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
+                               s.ptype.as<double>()));
+        HIPCHK(hipEventRecord(ev[3], ctx->stream));
+        SPHX_TRY(sphx_loop_step_sums(ctx, n, k, ctx->loop_d));
+        HIPCHK(hipEventRecord(ev[4], ctx->stream));
+        HIPCHK(hipEventRecord(ev[5], ctx->stream));
+        if (ctx->drag)
+            SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
+                                    s.mcs.as<double>()));
+    } else {
     SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
                        s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
                        s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
@@ -444,6 +470,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     if (ctx->drag)
         SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                 s.mcs.as<double>()));
+    }
     HIPCHK(hipEventRecord(ev[6], ctx->stream));
     if (ctx->gravity) {                          // drv:448-449; softening = median(h), nsc:358
         SPHX_TRY(sphx_ensure(ctx, ctx->grav, (size_t)n * 3 * sizeof(double)));

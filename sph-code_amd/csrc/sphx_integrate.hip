@@ -161,6 +161,7 @@ struct IntegArgs {
     const double *ha, *va, *vh;                        // hydro_update outputs (reference sign)
     const double *rho, *rhod, *drag_on, *drag_re;      // drag terms (drag_on == nullptr: none)
     const double* grav;                                // self-gravity (nullptr: none)
+    const double* G;                                   // loop-form mode: del_pressure (physical sign); nullptr otherwise
     const double* dt;
     double m_h, kB;
 };
@@ -173,8 +174,13 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     double pa[3], vis[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        pa[c] = nan_to_num(-a.ha[3 * (size_t)i + c] * g);     // physical sign, drv:460
-        vis[c] = nan_to_num(-a.va[3 * (size_t)i + c] * g);
+        if (a.G) {                                            // loop forms carry the physical sign themselves
+            pa[c] = nan_to_num(a.G[3 * (size_t)i + c] / a.rho[i] * g);      // drv:460
+            vis[c] = a.va[3 * (size_t)i + c];                               // av[0], drv:473
+        } else {
+            pa[c] = nan_to_num(-a.ha[3 * (size_t)i + c] * g);     // physical sign, drv:460
+            vis[c] = nan_to_num(-a.va[3 * (size_t)i + c] * g);
+        }
         if (a.drag_on) {                                      // drv:462-463,473
             const double dg = nan_to_num(a.drag_on[3 * (size_t)i + c] * a.rhod[i] / a.rho[i] * g);
             vis[c] = dg + nan_to_num(a.drag_re[3 * (size_t)i + c]) + vis[c];
@@ -218,6 +224,7 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n) {
     a.drag_on = ctx->drag ? ctx->drag_on.as<double>() : nullptr;
     a.drag_re = ctx->drag ? ctx->drag_re.as<double>() : nullptr;
     a.grav = ctx->gravity ? ctx->grav.as<double>() : nullptr;
+    a.G = ctx->loop_forms ? ctx->G.as<double>() : nullptr;
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);

@@ -15,7 +15,8 @@ from ._lib import dp, f64
 
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
-                 incremental=False, with_drag=False, gravity=None, G=6.67430e-11, clip_grad=False):
+                 incremental=False, with_drag=False, gravity=None, G=6.67430e-11, clip_grad=False,
+                 forms="hydro_update", d=None):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -35,6 +36,12 @@ class Simulation:
             dp(f64(state["mu_array"], (n,))), dp(f64(state["gamma_array"], (n,))),
             dp(f64(state["E_internal"], (n,))), dp(acc)))
         c.check(c.lib.sphx_set_clip_grad(c.h, 1 if clip_grad else 0))
+        if forms not in ("hydro_update", "loop"):
+            raise ValueError("forms must be 'hydro_update' or 'loop'")
+        if forms == "loop":            # the reference's time loop: nsc.density, del_pressure, ... with the global d
+            if d is None:
+                raise ValueError("forms='loop' needs the driver's global d (code_running.py:67-68)")
+            c.check(c.lib.sphx_state_set_loop_forms(c.h, 1, float(d)))
         if gravity is not None:
             if gravity not in ("direct", "tree"):
                 raise ValueError("gravity must be None, 'direct' or 'tree'")

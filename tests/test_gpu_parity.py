@@ -299,6 +299,41 @@ def test_clip_grad_option_vs_oracle_and_stability(nsc):
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("workload,with_drag", [("uniform_cube", False), ("dusty_sphere", True)])
+def test_loop_form_step_vs_oracle(workload, with_drag):
+    """Step mode forms='loop' (sphx_state_set_loop_forms): the reference's time loop as written - loop forms
+    with the global d, clipped gradients - on the reference's own IC (uniform cube, drv:62,132) and on a dusty
+    sphere with drag, 10 steps against oracle.step_loop (whose loop forms are pinned by the golden vectors).
+    The cloud stays quiet, so every particle is compared against the cloud's size."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K, nsteps = 4096, 40, 10
+    s0 = ics.WORKLOADS[workload](n)
+    from scipy.spatial import cKDTree
+    h0 = cKDTree(s0["points"]).query(s0["points"], k=K)[0][:, -1]
+    gasm = s0["mass"][s0["particle_type"] == 0]
+    d = float(np.median(h0) / np.median((gasm / orc.M_0) ** (1. / 3.)))      # h(m) comparable to the kNN radius
+    sim = Simulation(s0, n_neigh=K, forms="loop", d=d, with_drag=with_drag)
+    ref = dict(s0)
+    for it in range(nsteps):
+        sim.step(1)
+        ref = orc.step_loop(ref, d, n_neigh=K, eps=0.0, first=(it == 0), with_drag=with_drag)
+        got = sim.download()
+        assert got["dt"] == pytest.approx(ref["dt"], rel=1e-12), "dt at step %d" % it
+    R0 = np.max(np.abs(s0["points"]))
+    assert np.max(np.abs(ref["points"])) < 10 * R0 and np.max(np.abs(ref["velocities"])) < 1e6     # a quiet cloud
+    tol = 1e-9 if with_drag else 1e-10                         # drag's reaction is a float-atomic scatter-add
+    assert np.max(np.abs(got["points"] - ref["points"])) <= tol * R0
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= tol * 10 * np.max(np.abs(ref["velocities"]))
+    assert np.max(np.abs(got["total_accel"] - ref["total_accel"])) <= 1e-9 * np.max(np.abs(ref["total_accel"]))
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-9)
+    np.testing.assert_allclose(got["num_densities"], ref["num_densities"], rtol=1e-9)
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
+    np.testing.assert_allclose(got["T"], ref["T"], rtol=1e-9)
+    assert np.any(got["total_accel"] != 0.0)
+
+
 def test_step_with_drag_vs_oracle():
     """Gas-dust drag inside the fused step (sphx_state_set_drag; nsc:719-742, drv:455-473) on a
     5 %-dust sphere vs the oracle's step(with_drag=True).  The reaction is a scatter-add with
