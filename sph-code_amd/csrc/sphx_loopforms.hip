@@ -362,56 +362,219 @@ extern "C" int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* p
 }
 
 // ---- the loop forms on the device-resident, cell-sorted state of the step loop ------------------
-// drv:451-458 as the reference's time loop calls them, one after the other, on the step's own
-// neighbour list (columns in storage order: the step runs without blob order in this mode):
+// drv:451-458 as the reference's time loop evaluates them, on the step's own neighbour list:
 //   rho = density, rho_dust = dust_density, n = num_dens, delp = del_pressure,
 //   (av accel, av heat) = artificial_viscosity(..., densities = rho, ...), ct = crossing_time.
-// These are the array-API kernels as they are (one scattered 8-B load per field and neighbour:
-// ~6.5 ms per step at 1e6 particles; per-particle tables for the pow() factors made it slower - two
-// more gathers per neighbour - so the next step for this mode is 64-B records as in sphx_sums.hip).
-__global__ __launch_bounds__(256) void soa_to_aos3_kernel(int n, const double* x, const double* y, const double* z,
-                                                          double* aos) {
+// Same expressions, in the same order of operations, as the array-API kernels above (which the golden
+// vectors pin) - but gathered the way sphx_sums.hip gathers: per-particle factors ((m/m_0)^(2/3) d^2,
+// (m_0/m)^3, the gradient prefactor, c_s, mu m_h) are worked out once per step into dense records, and
+// the six sums run as two passes of one thread per particle with four neighbours in flight
+// (6.5 ms -> ~1 ms per step at 1e6 particles: the array-API kernels issue one scattered 8-B load per
+// field and neighbour and call pow() per neighbour).
+struct RecLA { double x, y, z, hq, m, a3, g1, pt; };     // pass 1: position, h(m)^2, mass, (m_0/m)^3, grad prefactor, type
+struct RecLB { double E, gam, mun, ds; };                // pass 1: E, gamma, mu m_h, sizes
+struct RecLV { double x, y, z, pt, vx, vy, vz, cs; };    // pass 2: position, type, velocity, sound speed
+struct RecLR { double rho, m; };                         // pass 2: density (from pass 1), mass
+
+struct LoopPrepArgs {
+    int n;
+    const double *x, *y, *z, *vx, *vy, *vz, *m, *pt, *h, *mu, *gam, *E, *T;
+    double d, m0, m_h, kB, amu;
+    RecLA* la; RecLB* lb; RecLV* lv;
+};
+__global__ __launch_bounds__(256) void loop_prep_kernel(LoopPrepArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const double m = a.m[i], d9 = pow9(a.d);
+    const double aa = a.m0 / m;
+    RecLA r;
+    r.x = a.x[i]; r.y = a.y[i]; r.z = a.z[i];
+    r.hq = pow(m / a.m0, 2.0 / 3.0) * (a.d * a.d);              // nsc:675
+    r.m = m;
+    r.a3 = aa * aa * aa;
+    r.g1 = -315.0 * 6.0 * (aa * aa * aa) / (PI64 * d9);          // nsc:688 up to (q*q) and the type mask
+    r.pt = a.pt[i];
+    a.la[i] = r;
+    RecLB b;
+    b.E = a.E[i]; b.gam = a.gam[i]; b.mun = a.mu[i] * a.m_h; b.ds = a.h[i];
+    a.lb[i] = b;
+    RecLV v;
+    v.x = r.x; v.y = r.y; v.z = r.z; v.pt = r.pt;
+    v.vx = a.vx[i]; v.vy = a.vy[i]; v.vz = a.vz[i];
+    v.cs = nan_to_num_d(sqrt(a.gam[i] * a.kB * a.T[i] / (a.mu[i] * a.amu)));     // nsc:792
+    a.lv[i] = v;
+}
+
+struct Q4L { double a, b, c, d; };
+__device__ __forceinline__ Q4L ld4(const double* p) {
+    const double2 lo = *reinterpret_cast<const double2*>(p);
+    const double2 hi = *reinterpret_cast<const double2*>(p + 2);
+    return Q4L{lo.x, lo.y, hi.x, hi.y};
+}
+#define LNB 4
+
+// pass 1: density (nsc:693), dust_density (nsc:704), num_dens (nsc:744), del_pressure (nsc:755)
+__global__ __launch_bounds__(256) void loop_pass1_kernel(int n, int npad, int k, double d9,
+                                                         const int* __restrict__ nbr,
+                                                         const RecLA* __restrict__ la,
+                                                         const RecLB* __restrict__ lb, double* rho, double* rhod,
+                                                         double* nden, double* G, RecLR* lr) {
+    const int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    aos[3 * (size_t)i] = x[i]; aos[3 * (size_t)i + 1] = y[i]; aos[3 * (size_t)i + 2] = z[i];
+    const double* sp = reinterpret_cast<const double*>(&la[i]);
+    const Q4L s0 = ld4(sp), s1 = ld4(sp + 4);
+    const double xi = s0.a, yi = s0.b, zi = s0.c, Ei = lb[i].E;
+    const bool gas_i = (s1.d == 0.0);
+    double s_rho = 0.0, s_d = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    for (int kk0 = 0; kk0 < k; kk0 += LNB) {
+        int jb[LNB];
+        Q4L q0b[LNB], q1b[LNB], q2b[LNB];
+#pragma unroll
+        for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+#pragma unroll
+        for (int u = 0; u < LNB; ++u) {
+            const int jj = jb[u] < 0 ? i : jb[u];
+            const double* q = reinterpret_cast<const double*>(&la[jj]);
+            q0b[u] = ld4(q); q1b[u] = ld4(q + 4);
+            q2b[u] = ld4(reinterpret_cast<const double*>(&lb[jj]));
+        }
+#pragma unroll
+        for (int u = 0; u < LNB; ++u) {
+            if (jb[u] < 0) continue;
+            const Q4L q0 = q0b[u], q1 = q1b[u], q2 = q2b[u];         // x y z hq | m a3 g1 pt | E gam mun ds
+            const double dx = q0.a - xi, dy = q0.b - yi, dz = q0.c - zi;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            const double q = q0.d - r2;
+            const double w = q1.a * 315.0 * q1.b * (q * q * q) / (PI64 * d9);        // Weigh2, nsc:673-676
+            const double vr = w * ((q1.d == 0.0) ? 1.0 : 0.0);
+            if (vr > 0.0) s_rho += vr;                                               // nsc:700
+            const double vn = w / q2.c;
+            if (vn > 0.0) s_n += vn;                                                 // nsc:751
+            if (q1.d == 2.0) {                                                       // Weigh2_dust, nsc:678-681
+                const double vd = weigh2_dust(r2, q1.a, q2.d);
+                if (vd > 0.0) s_d += vd;                                             // nsc:715
+            }
+            if (gas_i) {                                                             // nsc:755-774
+                double c = q1.c * (q * q) * ((q1.d == 0.0) ? 1.0 : 0.0);
+                c = (q > 0.0) ? c : 0.0;
+                const double f = (q2.a + Ei) / q2.b;
+                gx += 0.5 * nan_to_num_d(c * dx) * f;
+                gy += 0.5 * nan_to_num_d(c * dy) * f;
+                gz += 0.5 * nan_to_num_d(c * dz) * f;
+            }
+        }
+    }
+    rho[i] = s_rho; rhod[i] = s_d; nden[i] = s_n;
+    G[3 * (size_t)i] = gx; G[3 * (size_t)i + 1] = gy; G[3 * (size_t)i + 2] = gz;
+    lr[i] = RecLR{s_rho, s1.a};
+}
+
+// pass 2: artificial_viscosity (nsc:788-816) and crossing_time (nsc:776-786)
+__global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k, double d9,
+                                                         const int* __restrict__ nbr,
+                                                         const RecLA* __restrict__ la,
+                                                         const RecLV* __restrict__ lv,
+                                                         const RecLR* __restrict__ lr,
+                                                         const double* __restrict__ h, double* va, double* vh,
+                                                         u64* ct_bits) {
+    __shared__ u64 sm[4];
+    const int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    u64 mine = 0x7FF0000000000000ull;
+    if (i < n) {
+        const double* sp = reinterpret_cast<const double*>(&lv[i]);
+        const Q4L s0 = ld4(sp), sv = ld4(sp + 4);                    // x y z pt | vx vy vz cs
+        double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
+        if (s0.d == 0.0) {
+            const double hq_i = la[i].hq, g1_i = la[i].g1;
+            const RecLR ri = lr[i];
+            double mx = 0.0;
+            for (int kk0 = 0; kk0 < k; kk0 += LNB) {
+                int jb[LNB];
+                Q4L q0b[LNB], qvb[LNB];
+                double2 rb[LNB];
+#pragma unroll
+                for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+#pragma unroll
+                for (int u = 0; u < LNB; ++u) {
+                    const int jj = jb[u] < 0 ? i : jb[u];
+                    const double* q = reinterpret_cast<const double*>(&lv[jj]);
+                    q0b[u] = ld4(q); qvb[u] = ld4(q + 4);
+                    rb[u] = *reinterpret_cast<const double2*>(&lr[jj]);
+                }
+#pragma unroll
+                for (int u = 0; u < LNB; ++u) {
+                    if (jb[u] < 0) continue;
+                    const Q4L q0 = q0b[u], qv = qvb[u];
+                    const double dvx = qv.a - sv.a, dvy = qv.b - sv.b, dvz = qv.c - sv.c;
+                    mx = fmax(mx, dvx * dvx + dvy * dvy + dvz * dvz);                 // nsc:780 (every neighbour)
+                    if (q0.d != 0.0) continue;                                        // sums over gas neighbours only
+                    const double dx = q0.a - s0.a, dy = q0.b - s0.b, dz = q0.c - s0.c;
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    double w = (dvx * dx + dvy * dy + dvz * dz) / sqrt(r2);
+                    w = (w > 0.0) ? 0.0 : w;
+                    w = nan_to_num_d(w);                                              // self pair: 0/0
+                    const double vsig = qv.d + sv.d - 3.0 * w;
+                    const double rho_ij = (rb[u].x + ri.rho) / 2.0;
+                    const double PI = -0.5 * vsig * w / rho_ij;
+                    const double q = hq_i - r2;                                       // h(m_i), nsc:805
+                    double c = g1_i * (q * q) * 1.0;
+                    c = (q > 0.0) ? c : 0.0;
+                    const double gwx = nan_to_num_d(c * dx), gwy = nan_to_num_d(c * dy), gwz = nan_to_num_d(c * dz);
+                    const double mb = (rb[u].y + ri.m) / 2.0;
+                    ax += mb * PI * gwx; ay += mb * PI * gwy; az += mb * PI * gwz;
+                    heat += 0.5 * mb * PI * (dvx * gwx + dvy * gwy + dvz * gwz);
+                }
+            }
+            const double ct = nan_to_num_d(h[i] / sqrt(mx));
+            if (ct > 0.0) mine = (u64)__double_as_longlong(ct);
+        }
+        va[3 * (size_t)i] = ax; va[3 * (size_t)i + 1] = ay; va[3 * (size_t)i + 2] = az;
+        vh[i] = heat;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 p = __shfl_xor(mine, o, 64);
+        mine = p < mine ? p : mine;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 r = sm[0];
+        for (int w = 1; w < 4; ++w) r = sm[w] < r ? sm[w] : r;
+        if (r != 0x7FF0000000000000ull) atomicMin(ct_bits, r);
+    }
 }
 
 int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
     StateArrays& st = ctx->st;
     const size_t nb = (size_t)n * sizeof(double);
-    SPHX_TRY(sphx_ensure(ctx, ctx->in_a, 3 * nb));
-    SPHX_TRY(sphx_ensure(ctx, ctx->in_b, 3 * nb));
     DevBuf* outs1[] = {&ctx->rho, &ctx->rhod, &ctx->nden, &ctx->vh};
     for (DevBuf* b : outs1) SPHX_TRY(sphx_ensure(ctx, *b, nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->va, 3 * nb));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_a, (size_t)n * sizeof(RecLA)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_v, (size_t)n * sizeof(RecLV)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_b, (size_t)n * sizeof(RecLB)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_r, (size_t)n * sizeof(RecLR)));
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(soa_to_aos3_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, st.x.as<double>(),
-                       st.y.as<double>(), st.z.as<double>(), ctx->in_a.as<double>());
-    hipLaunchKernelGGL(soa_to_aos3_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, st.vx.as<double>(),
-                       st.vy.as<double>(), st.vz.as<double>(), ctx->in_b.as<double>());
-    LoopArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n = (int)n; a.npad = (int)sphx_pad64(n); a.k = k;
-    a.nbr = ctx->nbr.as<int>();
-    a.pos = ctx->in_a.as<double>(); a.vel = ctx->in_b.as<double>();
-    a.m = st.m.as<double>(); a.pt = st.ptype.as<double>(); a.h = st.hprev.as<double>();
-    a.mu = st.mu.as<double>(); a.gam = st.gam.as<double>(); a.E = st.E.as<double>(); a.T = st.T.as<double>();
-    a.d = d; a.m0 = ctx->cst.m_0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.amu = ctx->cst.amu;
-    a.out1 = ctx->rho.as<double>();
-    LAUNCH1(loop_density_kernel<0>);                                  // drv:451
-    a.out1 = ctx->rhod.as<double>();
-    LAUNCH1(loop_density_kernel<1>);                                  // drv:452
-    a.out1 = ctx->nden.as<double>();
-    LAUNCH1(loop_density_kernel<2>);                                  // drv:453
-    a.out3 = ctx->G.as<double>();
-    LAUNCH1(loop_del_pressure_kernel);                                // drv:456
-    a.rho = ctx->rho.as<double>();
-    a.out3 = ctx->va.as<double>(); a.out1 = ctx->vh.as<double>();
-    LAUNCH1(loop_av_kernel);                                          // drv:458
+    LoopPrepArgs p;
+    p.n = (int)n;
+    p.x = st.x.as<double>(); p.y = st.y.as<double>(); p.z = st.z.as<double>();
+    p.vx = st.vx.as<double>(); p.vy = st.vy.as<double>(); p.vz = st.vz.as<double>();
+    p.m = st.m.as<double>(); p.pt = st.ptype.as<double>(); p.h = st.hprev.as<double>();
+    p.mu = st.mu.as<double>(); p.gam = st.gam.as<double>(); p.E = st.E.as<double>(); p.T = st.T.as<double>();
+    p.d = d; p.m0 = ctx->cst.m_0; p.m_h = ctx->cst.m_h; p.kB = ctx->cst.k_B; p.amu = ctx->cst.amu;
+    p.la = ctx->lrec_a.as<RecLA>(); p.lb = ctx->lrec_b.as<RecLB>(); p.lv = ctx->lrec_v.as<RecLV>();
+    hipLaunchKernelGGL(loop_prep_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
+    const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
+    hipLaunchKernelGGL(loop_pass1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k, d9,
+                       ctx->nbr.as<int>(), p.la, p.lb, ctx->rho.as<double>(), ctx->rhod.as<double>(),
+                       ctx->nden.as<double>(), ctx->G.as<double>(), ctx->lrec_r.as<RecLR>());
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));       // 0x7F7F.. = huge finite "none yet"
-    a.ct_bits = ct;
-    LAUNCH1(loop_ct_kernel);                                          // drv:222
+    hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k, d9,
+                       ctx->nbr.as<int>(), p.la, p.lv, ctx->lrec_r.as<RecLR>(), st.hprev.as<double>(),
+                       ctx->va.as<double>(), ctx->vh.as<double>(), ct);
+    HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
