@@ -572,11 +572,13 @@ extern "C" int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, doub
 
 extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
     if (!ctx || !out) return SPHX_E_ARG;
+    SPHX_TRY(sphx_dev_collect(ctx));
     *out = ctx->stats;
     return SPHX_OK;
 }
 extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
     if (!ctx) return SPHX_E_ARG;
+    SPHX_TRY(sphx_dev_collect(ctx));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_CAND, 0, 2 * sizeof(u64), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -50,6 +50,19 @@ __global__ __launch_bounds__(256) void inject_field_kernel(int n, const int* per
         if (!(p)) return sphx_set_err(ctx, SPHX_E_ARG, "%s: argument %s is NULL", __func__, #p); \
     } while (0)
 
+// fold the kNN launch time of the last sphx_dev_search into the statistics (events on the library's stream)
+int sphx_dev_collect(sphx_ctx* ctx) {
+    if (!ctx->dev_ev_pending) return SPHX_OK;
+    ctx->dev_ev_pending = false;
+    HIPCHK(hipEventSynchronize(ctx->ev[2]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->stats.ms_search += ms;
+    ctx->stats.steps += 1;
+    ctx->stats.n = ctx->map_nactive;
+    return SPHX_OK;
+}
+
 extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, int k, const double* pos,
                                const double* hint, double rscale, double dist, double* h_out) {
     if (!ctx) return SPHX_E_ARG;
@@ -59,6 +72,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
                             (long long)n_owned);
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_dev_collect(ctx));
     const int64_t n = n_total;
     const size_t nb = (size_t)n * sizeof(double);
     ctx->map_perm = nullptr;
@@ -89,9 +103,12 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     o.h_sorted = nullptr; o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr;
     o.h_by_id = h_out;
     ctx->knn_hint_by_id = (hint != nullptr);
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     int rc = sphx_knn(ctx, n, k, xs, ys, zs, ctx->perm.as<int>(), ctx->inv.as<int>(), hint,
                       rscale > 0.0 ? rscale : ctx->rscale, dist, o);
     ctx->knn_hint_by_id = false;
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->dev_ev_pending = (rc == SPHX_OK);
     if (rc == SPHX_OK && ctx->qorder && ctx->use_lds) rc = sphx_blob_translate(ctx, n, k);
     return rc;
 }

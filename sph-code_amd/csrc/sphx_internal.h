@@ -86,6 +86,7 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
+    bool dev_ev_pending = false;  // sphx_dev_search recorded ev[1]/ev[2] around its kNN launch: not yet read
     int loop_forms = 0;           // step mode: the loop forms of the reference's time loop (sphx_state_set_loop_forms)
     double loop_d = 0.0;          // their global d (drv:68)
     DevBuf lrec_a, lrec_b, lrec_v, lrec_r;   // loop-form records (sphx_loopforms.hip)
@@ -198,6 +199,7 @@ int sphx_gravity_launch(sphx_ctx* ctx, int64_t n, const double* x, const double*
 int sphx_gravity_tree_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
                              const double* m, int ws, const double* eps_dev, double eps, double G, const int* omap,
                              double* acc);
+int sphx_dev_collect(sphx_ctx* ctx);
 int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d);
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);

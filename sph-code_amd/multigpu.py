@@ -654,6 +654,7 @@ def bench_main(args, rank, local_rank, world):
         sim.step()
     sim.ex.bytes_sent = 0
     sim.stats.update(ghosts=0, redo=0, migrated=0)
+    be.ctx.reset_stats()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -672,6 +673,7 @@ def bench_main(args, rank, local_rank, world):
     chk = torch.stack([torch.sqrt(v2.max()) if v2.numel() else v2.new_zeros(()),
                        (~torch.isfinite(sim.s["pos"])).sum().to(torch.float64)]).to(comm_dev)
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+    kst = be.ctx.stats()                     # rank 0's kNN launches: HIP events on the stream they ran on
     if rank == 0:
         t = float(tmax[0])
         total = float(cnt[0])
@@ -688,6 +690,11 @@ def bench_main(args, rank, local_rank, world):
                        "backend": backend, "cloud_size_scale": scale},
             "state_check": {"finite": float(chk[1]) == 0.0, "max_speed_m_s": float(chk[0]),
                             "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
+            "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "knn_kernel<0,2> (rank 0)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,
+                                        "peak": 8000.0, "unit": "GB/s", "frac": 192.0 * q / (ms * 1e-3) / 1e9 / 8000.0,
+                                        "traffic": None, "algorithmic_bytes_per_launch": 192.0 * q,
+                                        "kernel_ms": ms, "queries_per_launch": q})(
+                kst["ms_search"] / max(kst["steps"], 1), sim.n_owned) if kst["steps"] else None,
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
                      "search_redos": float(cnt[3])},
             "step_model": {"algorithmic_bytes_per_particle_step": 1248,
