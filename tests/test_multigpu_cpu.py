@@ -178,3 +178,14 @@ def test_world4_gloo_runs(tmp_path):
     ref = _reference(n, nsteps, "uniform_sphere")
     np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
     np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+
+
+def test_world8_gloo_runs(tmp_path):
+    """The rank count of the node's scaling run: 2 x 2 x 2 regions, every rank with 7 possible peers."""
+    n, nsteps = 4000, 2
+    got = _run_world(8, n, nsteps, "polytrope", tmp_path)
+    ref = _reference(n, nsteps, "polytrope")
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-13)
+    assert len(set(got["dt"])) == 1
