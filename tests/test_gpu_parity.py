@@ -504,3 +504,32 @@ def test_full_size_properties(nsc):
         assert np.array_equal(a, b, equal_nan=True)
     # species sums are consistent with the number density: sum_s F[s] / sum_s f_un ~ n
     np.testing.assert_allclose(out[5].sum(axis=0), out[4] * s["f_un"].sum(axis=1)[0], rtol=1e-12)
+
+
+@pytest.mark.timeout(180)
+def test_degenerate_states_do_not_hang_the_step():
+    """States no physical run should reach, but a diverging one does (the reference's scheme):
+    coincident particles (h = 0), a NaN / inf coordinate, a zero mass, fewer particles than K.  The step
+    must come back (results may be NaN where the reference's formulas give NaN) and stay usable."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    base = ics.uniform_sphere(600)
+    cases = {}
+    s = {k_: (v.copy() if hasattr(v, "copy") else v) for k_, v in base.items()}
+    s["points"][:300] = s["points"][0]                       # 300 coincident particles: h = 0 for them
+    cases["coincident"] = s
+    s = {k_: (v.copy() if hasattr(v, "copy") else v) for k_, v in base.items()}
+    s["points"][5, 0] = np.nan; s["points"][6, 1] = np.inf; s["velocities"][7, 2] = np.nan
+    s["mass"] = s["mass"].copy(); s["mass"][8] = 0.0
+    cases["nonfinite"] = s
+    cases["n_less_than_k"] = {k_: (v[:17].copy() if hasattr(v, "shape") and v.shape[:1] == (600,) else v)
+                              for k_, v in base.items()}
+    for name, st in cases.items():
+        for kw in ({}, {"forms": "loop", "d": 1e19}, {"gravity": "tree"}, {"clip_grad": True}):
+            sim = Simulation(st, n_neigh=40, **kw)
+            sim.step(3)
+            out = sim.download()
+            n = len(st["points"])
+            assert out["points"].shape == (n, 3) and out["sizes"].shape == (n,), (name, kw)
+            if name == "n_less_than_k" and not kw:
+                assert np.isfinite(out["points"]).all()
