@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void loop_pass1_kernel(int n, int npad, int k,
 }
 
 // pass 2: artificial_viscosity (nsc:788-816) and crossing_time (nsc:776-786)
-__global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k, double d9,
+__global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
                                                          const int* __restrict__ nbr,
                                                          const RecLA* __restrict__ la,
                                                          const RecLV* __restrict__ lv,
@@ -572,7 +572,7 @@ int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
                        ctx->nden.as<double>(), ctx->G.as<double>(), ctx->lrec_r.as<RecLR>());
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));       // 0x7F7F.. = huge finite "none yet"
-    hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k, d9,
+    hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k,
                        ctx->nbr.as<int>(), p.la, p.lv, ctx->lrec_r.as<RecLR>(), st.hprev.as<double>(),
                        ctx->va.as<double>(), ctx->vh.as<double>(), ct);
     HIPCHK(hipGetLastError());
