@@ -75,6 +75,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
     ctx->own_stream = ctx->stream;
     for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = sphx_ensure(ctx, ctx->scal, SC_NSLOTS * 8) == SPHX_OK &&
                  hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess;
     if (!ok) {
@@ -114,6 +117,9 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     for (int i = 0; i < 10; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -441,6 +447,9 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     StateArrays& s = ctx->st;
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
+    // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side
+    const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
+    if (fork) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
@@ -457,10 +466,23 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                     s.mcs.as<double>()));
     } else {
-    SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
-                       s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
-                       s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
-                       s.ptype.as<double>()));
+    {
+        hipStream_t main_stream = ctx->stream;
+        if (fork) {
+            HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+            ctx->stream = ctx->side_stream;
+        }
+        const int rc_prep = sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
+                                      s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr,
+                                      s.m.as<double>(), s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(),
+                                      s.gam.as<double>(), s.ptype.as<double>());
+        ctx->stream = main_stream;
+        if (rc_prep != SPHX_OK) return rc_prep;
+        if (fork) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+    }
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     SPHX_TRY(sphx_pass_density(ctx, n, k));
     HIPCHK(hipEventRecord(ev[4], ctx->stream));

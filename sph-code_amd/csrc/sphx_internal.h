@@ -72,6 +72,8 @@ struct sphx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream every launch goes to (own_stream or the caller's)
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;  // independent work beside the main chain (record build while the lists are deduplicated)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double dev_hmean = 0.0;             // device API: mean h of the previous search (cell size)
     bool knn_hint_by_id = false;        // device API: search-radius hints are in caller order
     char err[512] = {0};
