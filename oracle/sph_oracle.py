@@ -14,9 +14,14 @@ Parity pinning: the reference ships no tests or golden vectors (SURVEY section 4
 this oracle is pinned against outputs of the reference itself, run in the build
 container by `tests/golden/make_golden.py` and committed as `tests/golden/*.npz`
 (`tests/test_oracle_golden.py`).  Two parts stay "parity unpinned" by the
-reference: the integrator/time-step control (`step`, `timestep`: the driver script
-is not runnable, SURVEY F11 - restated from text drv:222-238,460-491) and the
-choice of which neighbours an eps=0.1 cKDTree traversal returns (SciPy-internal).
+reference: the integrator/time-step control (`step`, `step_loop`, `timestep`: the driver
+script is not runnable, SURVEY F11 - restated from text drv:222-238,460-491; `step_loop`
+composes the PINNED loop forms the way drv:451-477 does) and the choice of which
+neighbours an eps=0.1 cKDTree traversal returns (SciPy-internal).  `gravity_direct` is
+the softened direct sum the reference's tree gravity (nsc:252-415) approximates: that
+routine can neither be run nor pinned, so parity with IT is unpinned and the sum is
+checked against closed forms only.  `clip_grad=True` in `hydro_update` / `step` is a
+physics option of the build, not the reference's arithmetic.
 """
 import numpy as np
 
