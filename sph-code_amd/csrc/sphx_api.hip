@@ -419,7 +419,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             SPHX_TRY(sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint));
         }
         SPHX_TRY(sphx_permute_state(ctx, n));
-        if (ctx->use_blob && !ctx->use_verlet && !ctx->loop_forms) SPHX_TRY(sphx_build_blob_order(ctx, n));
+        if (ctx->use_blob && !ctx->use_verlet) SPHX_TRY(sphx_build_blob_order(ctx, n));
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         StateArrays& r = ctx->st;
         KnnOut o;
@@ -450,7 +450,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side
     const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
     if (fork) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-    if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
+    if (ctx->qorder && ctx->use_lds && !ctx->loop_forms) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
         if (ctx->drag)

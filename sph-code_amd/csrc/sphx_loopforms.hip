@@ -417,10 +417,12 @@ __device__ __forceinline__ Q4L ld4(const double* p) {
 __global__ __launch_bounds__(256) void loop_pass1_kernel(int n, int npad, int k, double d9,
                                                          const int* __restrict__ nbr,
                                                          const RecLA* __restrict__ la,
-                                                         const RecLB* __restrict__ lb, double* rho, double* rhod,
+                                                         const RecLB* __restrict__ lb,
+                                                         const int* __restrict__ qorder, double* rho, double* rhod,
                                                          double* nden, double* G, RecLR* lr) {
-    const int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;      // list column (blob order)
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;                                           // stored particle
     const double* sp = reinterpret_cast<const double*>(&la[i]);
     const Q4L s0 = ld4(sp), s1 = ld4(sp + 4);
     const double xi = s0.a, yi = s0.b, zi = s0.c, Ei = lb[i].E;
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256) void loop_pass1_kernel(int n, int npad, int k,
         int jb[LNB];
         Q4L q0b[LNB], q1b[LNB], q2b[LNB];
 #pragma unroll
-        for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+        for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
         for (int u = 0; u < LNB; ++u) {
             const int jj = jb[u] < 0 ? i : jb[u];
@@ -475,12 +477,14 @@ __global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
                                                          const RecLA* __restrict__ la,
                                                          const RecLV* __restrict__ lv,
                                                          const RecLR* __restrict__ lr,
-                                                         const double* __restrict__ h, double* va, double* vh,
+                                                         const double* __restrict__ h,
+                                                         const int* __restrict__ qorder, double* va, double* vh,
                                                          u64* ct_bits) {
     __shared__ u64 sm[4];
-    const int i = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     u64 mine = 0x7FF0000000000000ull;
-    if (i < n) {
+    if (p < n) {
+        const int i = qorder ? qorder[p] : p;
         const double* sp = reinterpret_cast<const double*>(&lv[i]);
         const Q4L s0 = ld4(sp), sv = ld4(sp + 4);                    // x y z pt | vx vy vz cs
         double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
                 Q4L q0b[LNB], qvb[LNB];
                 double2 rb[LNB];
 #pragma unroll
-                for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + i] : -1;
+                for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
                 for (int u = 0; u < LNB; ++u) {
                     const int jj = jb[u] < 0 ? i : jb[u];
@@ -568,12 +572,12 @@ int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
     hipLaunchKernelGGL(loop_prep_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
     const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
     hipLaunchKernelGGL(loop_pass1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k, d9,
-                       ctx->nbr.as<int>(), p.la, p.lb, ctx->rho.as<double>(), ctx->rhod.as<double>(),
+                       ctx->nbr.as<int>(), p.la, p.lb, ctx->qorder, ctx->rho.as<double>(), ctx->rhod.as<double>(),
                        ctx->nden.as<double>(), ctx->G.as<double>(), ctx->lrec_r.as<RecLR>());
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));       // 0x7F7F.. = huge finite "none yet"
     hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k,
-                       ctx->nbr.as<int>(), p.la, p.lv, ctx->lrec_r.as<RecLR>(), st.hprev.as<double>(),
+                       ctx->nbr.as<int>(), p.la, p.lv, ctx->lrec_r.as<RecLR>(), st.hprev.as<double>(), ctx->qorder,
                        ctx->va.as<double>(), ctx->vh.as<double>(), ct);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
