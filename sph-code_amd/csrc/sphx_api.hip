@@ -105,7 +105,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
-                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->grav_pyr, &ctx->grav_cell, &ctx->lrec_a, &ctx->lrec_b, &ctx->lrec_v, &ctx->lrec_r, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
+                     &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->grav_pyr, &ctx->grav_cell, &ctx->lrec_a, &ctx->lrec_v, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
@@ -450,7 +450,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side
     const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
     if (fork) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-    if (ctx->qorder && ctx->use_lds && !ctx->loop_forms) SPHX_TRY(sphx_blob_translate(ctx, n, k));
+    if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
         if (ctx->drag)

@@ -21,27 +21,11 @@
 // A reference that found no free entry within BLOB_PROBES probes (blobs with more than ~900
 // distinct neighbours; the most seen at BLOB_P = 128 is ~800) keeps the 0xFFFE marker and is
 // fetched from global memory through the int32 list.
-#include "sphx_internal.h"
+#include "sphx_blob.h"
 #pragma clang fp contract(off)
 #include <float.h>
 #include <stdlib.h>
 #include <stdio.h>
-
-#define BLOB_P 128                  // particles per workgroup
-#define BLOB_T 256                  // threads of the dedup kernel (two per particle)
-#define LPP SPHX_SUM_PARTS           // lanes per particle in the passes = partial sums per total
-#define PASS_T (BLOB_P * LPP)       // threads per workgroup of the passes
-#define BLOB_S 960                  // hash-table entries = image slots
-#define BLOB_PROBES 96
-#define SLOT_NONE 0xFFFFu           // no neighbour (list shorter than K)
-#define SLOT_OVER 0xFFFEu           // neighbour not staged: read it from global memory
-#define DD_BATCH 8                  // list entries fetched together per lane by the dedup kernel
-
-typedef unsigned short u16;
-
-__device__ __forceinline__ unsigned slot_hash(int j) {
-    return (unsigned)(((u64)((unsigned)j * 2654435761u) * (u64)BLOB_S) >> 32);
-}
 
 // ---- once per step: distinct neighbours of each workgroup ------------------------------------
 __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int k, int slots,
@@ -111,116 +95,6 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
     return SPHX_OK;
 }
 
-// ---- helpers -----------------------------------------------------------------------------------
-struct Q4 { double a, b, c, d; };
-__device__ __forceinline__ Q4 gload4(const double* p) {
-    const double2 lo = *reinterpret_cast<const double2*>(p);
-    const double2 hi = *reinterpret_cast<const double2*>(p + 2);
-    return Q4{lo.x, lo.y, hi.x, hi.y};
-}
-// chunks 2c, 2c+1 of slot s
-__device__ __forceinline__ Q4 lload4(const double2* img, int s, int c2) {
-    const double2 lo = img[(2 * c2) * BLOB_S + s];
-    const double2 hi = img[(2 * c2 + 1) * BLOB_S + s];
-    return Q4{lo.x, lo.y, hi.x, hi.y};
-}
-// sqrt for the distances of the neighbour loops: the library's correctly rounded sequence (v_rsq_f64
-// seed, two coupled Newton steps on g ~ sqrt(x), h ~ 1/(2 sqrt(x)), residual corrections) without its
-// exponent rescaling and class checks - squared distances here are 0 or sit mid-range (1e20..1e45 m^2).
-// Measured: library sqrt = 18 fp64-multiply issue slots, this = 11 (a pass spends ~80 per neighbour).
-// Bit-identical to sqrt() on that range (test_step_loop_variants_are_bit_identical compares against
-// the gather kernels, which call sqrt()).
-__device__ __forceinline__ double sqrt_mid(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d0 = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d0, h, g);
-    const double d1 = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d1, h, g);
-    return x > 0.0 ? g : 0.0;
-}
-
-// the value held by the other lane of the pair (lane ^ 1), moved inside the VALU
-__device__ __forceinline__ double pair_swap(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double pair_swap2(double v) {                                   // lane ^ 2
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x4E, 0xF, 0xF, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-// total of the particle's LPP partial sums, in the fixed order (p0 + p1) [+ (p2 + p3)] that the gather
-// kernels use as well (valid in every lane of the group)
-__device__ __forceinline__ double group_total(double acc) {
-    acc = acc + pair_swap(acc);
-    if (LPP == 4) acc = acc + pair_swap2(acc);
-    return acc;
-}
-__device__ __forceinline__ double group_max(double v) {
-    v = fmax(v, pair_swap(v));
-    if (LPP == 4) v = fmax(v, pair_swap2(v));
-    return v;
-}
-
-#define NSTAGE ((BLOB_S + PASS_T - 1) / PASS_T)
-#define NB (8 / LPP) // neighbours in flight per lane (one batch = 8 list positions)
-#define KPAD(k) ((((k) + 7) / 8) * 8)      // slot tile rows: whole batches
-#define IMG_BYTES(per_slot, k) ((size_t)BLOB_S * (per_slot) + (size_t)KPAD(k) * BLOB_P * sizeof(u16))
-
-// Fill the workgroup's LDS: slot lists (16-B pieces; rows k..KPAD(k) read as "no neighbour") and the
-// records of the occupied table entries.  NSIDE 1: one 8-B side value per slot.  NSIDE 2 (pass 3):
-// g0 replaces the record's last double (cs, unused there) and g1 is the side value.  All global
-// loads are issued before the first use.
-template <int NSIDE, class Rec>
-__device__ __forceinline__ void stage(double2* img, double* side, u16* tile, const Rec* __restrict__ rec,
-                                      const double* __restrict__ g0, int g0_stride,
-                                      const double* __restrict__ g1, int g1_stride,
-                                      const int* __restrict__ uq, const u16* __restrict__ slot16, int npad,
-                                      int k, int b) {
-    int ju[NSTAGE];
-#pragma unroll
-    for (int r = 0; r < NSTAGE; ++r) {
-        const int s = threadIdx.x + r * PASS_T;
-        ju[r] = (s < BLOB_S) ? uq[s] : -1;
-    }
-    const int pieces = KPAD(k) * (BLOB_P / 8);
-    for (int q = threadIdx.x; q < pieces; q += PASS_T) {
-        const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
-        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (kk < k) v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
-        *reinterpret_cast<uint4*>(tile + kk * BLOB_P + c * 8) = v;
-    }
-    double2 c[NSTAGE][4];
-    double e0[NSTAGE], e1[NSTAGE];
-#pragma unroll
-    for (int r = 0; r < NSTAGE; ++r) {
-        const int j = ju[r] < 0 ? 0 : ju[r];
-        const double2* g = reinterpret_cast<const double2*>(&rec[j]);       // empty entry: particle 0, not stored
-        c[r][0] = g[0]; c[r][1] = g[1]; c[r][2] = g[2]; c[r][3] = g[3];
-        e0[r] = (NSIDE > 0) ? g0[(size_t)j * g0_stride] : 0.0;
-        e1[r] = (NSIDE > 1) ? g1[(size_t)j * g1_stride] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < NSTAGE; ++r) {
-        const int s = threadIdx.x + r * PASS_T;
-        if (ju[r] >= 0) {
-            if (NSIDE == 2) c[r][3].y = e0[r];
-            img[0 * BLOB_S + s] = c[r][0]; img[1 * BLOB_S + s] = c[r][1];
-            img[2 * BLOB_S + s] = c[r][2]; img[3 * BLOB_S + s] = c[r][3];
-            if (NSIDE == 1) side[s] = e0[r];
-            if (NSIDE == 2) side[s] = e1[r];
-        }
-    }
-}
-
 // A batch of NB list positions of this lane.  FAST: every lane of the wave has a staged neighbour at
 // each of them (the usual case): straight-line LDS reads and arithmetic, nothing to branch on.
 // Otherwise a position may be empty (skipped) or unstaged (fetched through the int32 list).
@@ -261,18 +135,6 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
         a.gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
         a.gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
     }
-}
-
-// the lane's slot numbers for batch m0 (tile rows beyond k hold SLOT_NONE)
-__device__ __forceinline__ void load_slots(unsigned (&sl)[NB], const u16* tile, int m0, int half, int t) {
-#pragma unroll
-    for (int u = 0; u < NB; ++u) sl[u] = tile[(LPP * (m0 + u) + half) * BLOB_P + t];
-}
-__device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
-    unsigned worst = sl[0];
-#pragma unroll
-    for (int u = 1; u < NB; ++u) worst = worst > sl[u] ? worst : sl[u];
-    return __ballot(worst >= SLOT_OVER) == 0ull;
 }
 
 // ---- pass 1: rho, rho_dust, n, grad P        nsc:588-619 --------------------------------------
@@ -577,7 +439,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, 
 
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
-static int blob_grid(sphx_ctx* ctx, int nblk) {
+int sphx_blob_grid(sphx_ctx* ctx, int nblk) {
     if (ctx->blob_grid <= 0) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -621,7 +483,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             HIPCHK(hipEventRecord(e0, ctx->stream));
 #define BLOB_EXP_LAUNCH(M)                                                                                           \
-            hipLaunchKernelGGL(blob_density_kernel<M>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
+            hipLaunchKernelGGL(blob_density_kernel<M>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
                                k, nblk, ctx->clip_grad, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, \
                                nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
             if (mode == 0) BLOB_EXP_LAUNCH(0);
@@ -636,7 +498,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
     }
-    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
+    hipLaunchKernelGGL(blob_density_kernel<0>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->rho.as<double>(),
@@ -649,7 +511,7 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_pi_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
+    hipLaunchKernelGGL(blob_pi_kernel, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(),
@@ -662,7 +524,7 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    hipLaunchKernelGGL(blob_visc_kernel, dim3(blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
+    hipLaunchKernelGGL(blob_visc_kernel, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),

@@ -91,7 +91,8 @@ struct sphx_ctx {
     bool dev_ev_pending = false;  // sphx_dev_search recorded ev[1]/ev[2] around its kNN launch: not yet read
     int loop_forms = 0;           // step mode: the loop forms of the reference's time loop (sphx_state_set_loop_forms)
     double loop_d = 0.0;          // their global d (drv:68)
-    DevBuf lrec_a, lrec_b, lrec_v, lrec_r;   // loop-form records (sphx_loopforms.hip)
+    DevBuf lrec_a, lrec_v;        // loop-form records (sphx_loopforms.hip)
+    bool loop_attr_set = false;
     int clip_grad = 0;            // physics option: neighbour-side gradient clipped beyond h_j (sphx_set_clip_grad)
     int gravity = 0;              // 1: direct-sum self-gravity each step (sphx_state_set_gravity)
     double grav_G = 0.0;

@@ -365,119 +365,164 @@ extern "C" int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* p
 // drv:451-458 as the reference's time loop evaluates them, on the step's own neighbour list:
 //   rho = density, rho_dust = dust_density, n = num_dens, delp = del_pressure,
 //   (av accel, av heat) = artificial_viscosity(..., densities = rho, ...), ct = crossing_time.
-// Same expressions, in the same order of operations, as the array-API kernels above (which the golden
-// vectors pin) - but gathered the way sphx_sums.hip gathers: per-particle factors ((m/m_0)^(2/3) d^2,
-// (m_0/m)^3, the gradient prefactor, c_s, mu m_h) are worked out once per step into dense records, and
-// the six sums run as two passes of one thread per particle with four neighbours in flight
-// (6.5 ms -> ~1 ms per step at 1e6 particles: the array-API kernels issue one scattered 8-B load per
-// field and neighbour and call pow() per neighbour).
-struct RecLA { double x, y, z, hq, m, a3, g1, pt; };     // pass 1: position, h(m)^2, mass, (m_0/m)^3, grad prefactor, type
-struct RecLB { double E, gam, mun, ds; };                // pass 1: E, gamma, mu m_h, sizes
-struct RecLV { double x, y, z, pt, vx, vy, vz, cs; };    // pass 2: position, type, velocity, sound speed
-struct RecLR { double rho, m; };                         // pass 2: density (from pass 1), mass
+// Same expressions as the array-API kernels above (which the golden vectors pin), organised the way
+// sphx_sums.hip / sphx_blob.hip organise hydro_update's sums: per-particle factors are worked out once
+// per step into dense 64-B records (+ one 8-B side value), the six sums run as two passes, sums are
+// kept as SPHX_SUM_PARTS partial sums over the list positions k mod SPHX_SUM_PARTS, and each pass
+// exists in a gather form (one thread per particle) and an LDS form (blob image, four lanes per
+// particle, sphx_blob.h) that agree bit for bit.
+//   pass 1 record {x y z hq | w1 g1 +-mun E}, side gamma:  hq = (m/m_0)^(2/3) d^2, w1 = m 315 (m_0/m)^3,
+//       g1 = -1890 (m_0/m)^3 / (64 pi d^9), mun = mu m_h carrying the gas flag in its sign
+//   pass 2 record {x y z +-cs | vx vy vz rho}, side m:       cs >= 0 for gas, -(cs + 1) otherwise
+// Dust neighbours (type 2, a few per cent at most) need m_j and sizes_j as well: fetched from global
+// memory through the int32 list.
+#include "sphx_blob.h"
+struct RecP1 { double x, y, z, hq, w1, g1, muns, E; };
+struct RecP2 { double x, y, z, css, vx, vy, vz, rho; };
 
 struct LoopPrepArgs {
     int n;
-    const double *x, *y, *z, *vx, *vy, *vz, *m, *pt, *h, *mu, *gam, *E, *T;
+    const double *x, *y, *z, *vx, *vy, *vz, *m, *pt, *mu, *gam, *E, *T;
     double d, m0, m_h, kB, amu;
-    RecLA* la; RecLB* lb; RecLV* lv;
+    RecP1* p1; RecP2* p2;
 };
 __global__ __launch_bounds__(256) void loop_prep_kernel(LoopPrepArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const double m = a.m[i], d9 = pow9(a.d);
     const double aa = a.m0 / m;
-    RecLA r;
+    const bool gas = (a.pt[i] == 0.0);
+    RecP1 r;
     r.x = a.x[i]; r.y = a.y[i]; r.z = a.z[i];
     r.hq = pow(m / a.m0, 2.0 / 3.0) * (a.d * a.d);              // nsc:675
-    r.m = m;
-    r.a3 = aa * aa * aa;
-    r.g1 = -315.0 * 6.0 * (aa * aa * aa) / (PI64 * d9);          // nsc:688 up to (q*q) and the type mask
-    r.pt = a.pt[i];
-    a.la[i] = r;
-    RecLB b;
-    b.E = a.E[i]; b.gam = a.gam[i]; b.mun = a.mu[i] * a.m_h; b.ds = a.h[i];
-    a.lb[i] = b;
-    RecLV v;
-    v.x = r.x; v.y = r.y; v.z = r.z; v.pt = r.pt;
+    r.w1 = m * 315.0 * (aa * aa * aa);                           // nsc:676, up to (q*q*q) / (64 pi d^9)
+    r.g1 = -315.0 * 6.0 * (aa * aa * aa) / (PI64 * d9);          // nsc:688, up to (q*q) and the type mask
+    const double mun = a.mu[i] * a.m_h;                          // nsc:751
+    r.muns = gas ? mun : -mun;
+    r.E = a.E[i];
+    a.p1[i] = r;
+    RecP2 v;
+    v.x = r.x; v.y = r.y; v.z = r.z;
+    const double cs = nan_to_num_d(sqrt(a.gam[i] * a.kB * a.T[i] / (a.mu[i] * a.amu)));     // nsc:792
+    v.css = gas ? cs : -(cs + 1.0);
     v.vx = a.vx[i]; v.vy = a.vy[i]; v.vz = a.vz[i];
-    v.cs = nan_to_num_d(sqrt(a.gam[i] * a.kB * a.T[i] / (a.mu[i] * a.amu)));     // nsc:792
-    a.lv[i] = v;
+    v.rho = 0.0;                                                 // pass 1 fills it in
+    a.p2[i] = v;
 }
 
-struct Q4L { double a, b, c, d; };
-__device__ __forceinline__ Q4L ld4(const double* p) {
-    const double2 lo = *reinterpret_cast<const double2*>(p);
-    const double2 hi = *reinterpret_cast<const double2*>(p + 2);
-    return Q4L{lo.x, lo.y, hi.x, hi.y};
+__device__ __forceinline__ double parts_total_l(const double (&a)[SPHX_SUM_PARTS]) {
+    if (SPHX_SUM_PARTS == 4) return (a[0] + a[1]) + (a[2] + a[3]);
+    return a[0] + a[SPHX_SUM_PARTS - 1];
 }
+
+// ---- terms of one neighbour (shared by the gather and the LDS kernels) -------------------------------
+struct L1Acc { double rho, rd, n, gx, gy, gz; };
+// q0 = {x y z hq}, q1 = {w1 g1 +-mun E}; (dm, dh) = mass and size of the neighbour if it is dust, else dm < 0
+__device__ __forceinline__ void loop1_term(L1Acc& a, const Q4& q0, const Q4& q1, double gam_j, double dm, double dh,
+                                           double xi, double yi, double zi, double Ei, bool gas_i, double d9) {
+    const double dx = q0.a - xi, dy = q0.b - yi, dz = q0.c - zi;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double q = q0.d - r2;
+    const double w = q1.a * (q * q * q) / (PI64 * d9);                           // Weigh2, nsc:673-676
+    const bool gas_j = q1.c > 0.0;
+    const double vr = w * (gas_j ? 1.0 : 0.0);
+    if (vr > 0.0) a.rho += vr;                                                   // nsc:700
+    const double vn = w / fabs(q1.c);
+    if (vn > 0.0) a.n += vn;                                                     // nsc:751
+    if (dm >= 0.0) {                                                             // Weigh2_dust, nsc:678-681
+        const double vd = weigh2_dust(r2, dm, dh);
+        if (vd > 0.0) a.rd += vd;                                                // nsc:715
+    }
+    if (gas_i) {                                                                 // nsc:755-774
+        double c = q1.b * (q * q) * (gas_j ? 1.0 : 0.0);
+        c = (q > 0.0) ? c : 0.0;
+        const double f = (q1.d + Ei) / gam_j;
+        a.gx += 0.5 * nan_to_num_d(c * dx) * f;
+        a.gy += 0.5 * nan_to_num_d(c * dy) * f;
+        a.gz += 0.5 * nan_to_num_d(c * dz) * f;
+    }
+}
+struct L2Acc { double ax, ay, az, heat; };
+// q0 = {x y z +-cs}, qv = {vx vy vz rho}; returns |dv|^2 (the crossing time takes every neighbour)
+__device__ __forceinline__ double loop2_term(L2Acc& a, const Q4& q0, const Q4& qv, double m_j, const Q4& s0,
+                                             const Q4& sv, double rho_i, double m_i, double hq_i, double g1_i) {
+    const double dvx = qv.a - sv.a, dvy = qv.b - sv.b, dvz = qv.c - sv.c;
+    const double rel = dvx * dvx + dvy * dvy + dvz * dvz;                         // nsc:780
+    if (q0.d < 0.0) return rel;                                                   // sums over gas neighbours only
+    const double dx = q0.a - s0.a, dy = q0.b - s0.b, dz = q0.c - s0.c;
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    double w = (dvx * dx + dvy * dy + dvz * dz) / sqrt(r2);
+    w = (w > 0.0) ? 0.0 : w;
+    w = nan_to_num_d(w);                                                          // self pair: 0/0
+    const double vsig = q0.d + s0.d - 3.0 * w;
+    const double rho_ij = (qv.d + rho_i) / 2.0;
+    const double PI = -0.5 * vsig * w / rho_ij;
+    const double q = hq_i - r2;                                                   // h(m_i), nsc:805
+    double c = g1_i * (q * q) * 1.0;
+    c = (q > 0.0) ? c : 0.0;
+    const double gwx = nan_to_num_d(c * dx), gwy = nan_to_num_d(c * dy), gwz = nan_to_num_d(c * dz);
+    const double mb = (m_j + m_i) / 2.0;
+    a.ax += mb * PI * gwx; a.ay += mb * PI * gwy; a.az += mb * PI * gwz;
+    a.heat += 0.5 * mb * PI * (dvx * gwx + dvy * gwy + dvz * gwz);
+    return rel;
+}
+
 #define LNB 4
-
+// ---- gather form ---------------------------------------------------------------------------------------
 // pass 1: density (nsc:693), dust_density (nsc:704), num_dens (nsc:744), del_pressure (nsc:755)
 __global__ __launch_bounds__(256) void loop_pass1_kernel(int n, int npad, int k, double d9,
                                                          const int* __restrict__ nbr,
-                                                         const RecLA* __restrict__ la,
-                                                         const RecLB* __restrict__ lb,
+                                                         const RecP1* __restrict__ p1,
+                                                         const double* __restrict__ gam,
+                                                         const double* __restrict__ pt, const double* __restrict__ m,
+                                                         const double* __restrict__ h,
                                                          const int* __restrict__ qorder, double* rho, double* rhod,
-                                                         double* nden, double* G, RecLR* lr) {
+                                                         double* nden, double* G, RecP2* p2) {
     const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;      // list column (blob order)
     if (p >= n) return;
     const int i = qorder ? qorder[p] : p;                                           // stored particle
-    const double* sp = reinterpret_cast<const double*>(&la[i]);
-    const Q4L s0 = ld4(sp), s1 = ld4(sp + 4);
-    const double xi = s0.a, yi = s0.b, zi = s0.c, Ei = lb[i].E;
-    const bool gas_i = (s1.d == 0.0);
-    double s_rho = 0.0, s_d = 0.0, s_n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    const double* sp = reinterpret_cast<const double*>(&p1[i]);
+    const Q4 s0 = gload4(sp), s1 = gload4(sp + 4);
+    const bool gas_i = s1.c > 0.0;
+    L1Acc acc[SPHX_SUM_PARTS] = {};
     for (int kk0 = 0; kk0 < k; kk0 += LNB) {
         int jb[LNB];
-        Q4L q0b[LNB], q1b[LNB], q2b[LNB];
+        Q4 q0b[LNB], q1b[LNB];
+        double gb[LNB];
 #pragma unroll
         for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
         for (int u = 0; u < LNB; ++u) {
             const int jj = jb[u] < 0 ? i : jb[u];
-            const double* q = reinterpret_cast<const double*>(&la[jj]);
-            q0b[u] = ld4(q); q1b[u] = ld4(q + 4);
-            q2b[u] = ld4(reinterpret_cast<const double*>(&lb[jj]));
+            const double* q = reinterpret_cast<const double*>(&p1[jj]);
+            q0b[u] = gload4(q); q1b[u] = gload4(q + 4);
+            gb[u] = gam[jj];
         }
 #pragma unroll
         for (int u = 0; u < LNB; ++u) {
             if (jb[u] < 0) continue;
-            const Q4L q0 = q0b[u], q1 = q1b[u], q2 = q2b[u];         // x y z hq | m a3 g1 pt | E gam mun ds
-            const double dx = q0.a - xi, dy = q0.b - yi, dz = q0.c - zi;
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            const double q = q0.d - r2;
-            const double w = q1.a * 315.0 * q1.b * (q * q * q) / (PI64 * d9);        // Weigh2, nsc:673-676
-            const double vr = w * ((q1.d == 0.0) ? 1.0 : 0.0);
-            if (vr > 0.0) s_rho += vr;                                               // nsc:700
-            const double vn = w / q2.c;
-            if (vn > 0.0) s_n += vn;                                                 // nsc:751
-            if (q1.d == 2.0) {                                                       // Weigh2_dust, nsc:678-681
-                const double vd = weigh2_dust(r2, q1.a, q2.d);
-                if (vd > 0.0) s_d += vd;                                             // nsc:715
-            }
-            if (gas_i) {                                                             // nsc:755-774
-                double c = q1.c * (q * q) * ((q1.d == 0.0) ? 1.0 : 0.0);
-                c = (q > 0.0) ? c : 0.0;
-                const double f = (q2.a + Ei) / q2.b;
-                gx += 0.5 * nan_to_num_d(c * dx) * f;
-                gy += 0.5 * nan_to_num_d(c * dy) * f;
-                gz += 0.5 * nan_to_num_d(c * dz) * f;
-            }
+            double dm = -1.0, dh = 0.0;
+            if (!(q1b[u].c > 0.0) && pt[jb[u]] == 2.0) { dm = m[jb[u]]; dh = h[jb[u]]; }
+            loop1_term(acc[u & (SPHX_SUM_PARTS - 1)], q0b[u], q1b[u], gb[u], dm, dh, s0.a, s0.b, s0.c, s1.d, gas_i, d9);
         }
     }
-    rho[i] = s_rho; rhod[i] = s_d; nden[i] = s_n;
-    G[3 * (size_t)i] = gx; G[3 * (size_t)i + 1] = gy; G[3 * (size_t)i + 2] = gz;
-    lr[i] = RecLR{s_rho, s1.a};
+    double t_rho[SPHX_SUM_PARTS], t_rd[SPHX_SUM_PARTS], t_n[SPHX_SUM_PARTS], t_x[SPHX_SUM_PARTS], t_y[SPHX_SUM_PARTS],
+        t_z[SPHX_SUM_PARTS];
+#pragma unroll
+    for (int q = 0; q < SPHX_SUM_PARTS; ++q) {
+        t_rho[q] = acc[q].rho; t_rd[q] = acc[q].rd; t_n[q] = acc[q].n; t_x[q] = acc[q].gx; t_y[q] = acc[q].gy; t_z[q] = acc[q].gz;
+    }
+    const double s_rho = parts_total_l(t_rho);
+    rho[i] = s_rho; rhod[i] = parts_total_l(t_rd); nden[i] = parts_total_l(t_n);
+    G[3 * (size_t)i] = parts_total_l(t_x); G[3 * (size_t)i + 1] = parts_total_l(t_y); G[3 * (size_t)i + 2] = parts_total_l(t_z);
+    p2[i].rho = s_rho;
 }
 
 // pass 2: artificial_viscosity (nsc:788-816) and crossing_time (nsc:776-786)
-__global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
-                                                         const int* __restrict__ nbr,
-                                                         const RecLA* __restrict__ la,
-                                                         const RecLV* __restrict__ lv,
-                                                         const RecLR* __restrict__ lr,
-                                                         const double* __restrict__ h,
+__global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                         const RecP1* __restrict__ p1,
+                                                         const RecP2* __restrict__ p2,
+                                                         const double* __restrict__ m, const double* __restrict__ h,
                                                          const int* __restrict__ qorder, double* va, double* vh,
                                                          u64* ct_bits) {
     __shared__ u64 sm[4];
@@ -485,50 +530,37 @@ __global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
     u64 mine = 0x7FF0000000000000ull;
     if (p < n) {
         const int i = qorder ? qorder[p] : p;
-        const double* sp = reinterpret_cast<const double*>(&lv[i]);
-        const Q4L s0 = ld4(sp), sv = ld4(sp + 4);                    // x y z pt | vx vy vz cs
+        const double* sp = reinterpret_cast<const double*>(&p2[i]);
+        const Q4 s0 = gload4(sp), sv = gload4(sp + 4);               // x y z +-cs | vx vy vz rho
         double ax = 0.0, ay = 0.0, az = 0.0, heat = 0.0;
-        if (s0.d == 0.0) {
-            const double hq_i = la[i].hq, g1_i = la[i].g1;
-            const RecLR ri = lr[i];
+        if (s0.d >= 0.0) {
+            const double hq_i = p1[i].hq, g1_i = p1[i].g1, m_i = m[i];
+            L2Acc acc[SPHX_SUM_PARTS] = {};
             double mx = 0.0;
             for (int kk0 = 0; kk0 < k; kk0 += LNB) {
                 int jb[LNB];
-                Q4L q0b[LNB], qvb[LNB];
-                double2 rb[LNB];
+                Q4 q0b[LNB], qvb[LNB];
+                double mb[LNB];
 #pragma unroll
                 for (int u = 0; u < LNB; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
 #pragma unroll
                 for (int u = 0; u < LNB; ++u) {
                     const int jj = jb[u] < 0 ? i : jb[u];
-                    const double* q = reinterpret_cast<const double*>(&lv[jj]);
-                    q0b[u] = ld4(q); qvb[u] = ld4(q + 4);
-                    rb[u] = *reinterpret_cast<const double2*>(&lr[jj]);
+                    const double* q = reinterpret_cast<const double*>(&p2[jj]);
+                    q0b[u] = gload4(q); qvb[u] = gload4(q + 4);
+                    mb[u] = m[jj];
                 }
 #pragma unroll
                 for (int u = 0; u < LNB; ++u) {
                     if (jb[u] < 0) continue;
-                    const Q4L q0 = q0b[u], qv = qvb[u];
-                    const double dvx = qv.a - sv.a, dvy = qv.b - sv.b, dvz = qv.c - sv.c;
-                    mx = fmax(mx, dvx * dvx + dvy * dvy + dvz * dvz);                 // nsc:780 (every neighbour)
-                    if (q0.d != 0.0) continue;                                        // sums over gas neighbours only
-                    const double dx = q0.a - s0.a, dy = q0.b - s0.b, dz = q0.c - s0.c;
-                    const double r2 = dx * dx + dy * dy + dz * dz;
-                    double w = (dvx * dx + dvy * dy + dvz * dz) / sqrt(r2);
-                    w = (w > 0.0) ? 0.0 : w;
-                    w = nan_to_num_d(w);                                              // self pair: 0/0
-                    const double vsig = qv.d + sv.d - 3.0 * w;
-                    const double rho_ij = (rb[u].x + ri.rho) / 2.0;
-                    const double PI = -0.5 * vsig * w / rho_ij;
-                    const double q = hq_i - r2;                                       // h(m_i), nsc:805
-                    double c = g1_i * (q * q) * 1.0;
-                    c = (q > 0.0) ? c : 0.0;
-                    const double gwx = nan_to_num_d(c * dx), gwy = nan_to_num_d(c * dy), gwz = nan_to_num_d(c * dz);
-                    const double mb = (rb[u].y + ri.m) / 2.0;
-                    ax += mb * PI * gwx; ay += mb * PI * gwy; az += mb * PI * gwz;
-                    heat += 0.5 * mb * PI * (dvx * gwx + dvy * gwy + dvz * gwz);
+                    mx = fmax(mx, loop2_term(acc[u & (SPHX_SUM_PARTS - 1)], q0b[u], qvb[u], mb[u], s0, sv, sv.d, m_i, hq_i,
+                                             g1_i));
                 }
             }
+            double t_x[SPHX_SUM_PARTS], t_y[SPHX_SUM_PARTS], t_z[SPHX_SUM_PARTS], t_h[SPHX_SUM_PARTS];
+#pragma unroll
+            for (int q = 0; q < SPHX_SUM_PARTS; ++q) { t_x[q] = acc[q].ax; t_y[q] = acc[q].ay; t_z[q] = acc[q].az; t_h[q] = acc[q].heat; }
+            ax = parts_total_l(t_x); ay = parts_total_l(t_y); az = parts_total_l(t_z); heat = parts_total_l(t_h);
             const double ct = nan_to_num_d(h[i] / sqrt(mx));
             if (ct > 0.0) mine = (u64)__double_as_longlong(ct);
         }
@@ -537,14 +569,147 @@ __global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const u64 p = __shfl_xor(mine, o, 64);
-        mine = p < mine ? p : mine;
+        const u64 q = __shfl_xor(mine, o, 64);
+        mine = q < mine ? q : mine;
     }
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 r = sm[0];
         for (int w = 1; w < 4; ++w) r = sm[w] < r ? sm[w] : r;
+        if (r != 0x7FF0000000000000ull) atomicMin(ct_bits, r);
+    }
+}
+
+// ---- LDS form (sphx_blob.h: blob image, LPP lanes per particle, persistent workgroups) ------------------
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n, int npad, int k, int nblk, double d9,
+                                                                          const int* __restrict__ nbr,
+                                                                          const u16* __restrict__ slot16,
+                                                                          const int* __restrict__ uniq,
+                                                                          const int* __restrict__ qorder,
+                                                                          const RecP1* __restrict__ p1,
+                                                                          const double* __restrict__ gam,
+                                                                          const double* __restrict__ pt,
+                                                                          const double* __restrict__ m,
+                                                                          const double* __restrict__ h, double* rho,
+                                                                          double* rhod, double* nden, double* G,
+                                                                          RecP2* p2) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, gamma, slot tile
+    double* lgam = reinterpret_cast<double*>(img + 4 * BLOB_S);
+    u16* tile = reinterpret_cast<u16*>(lgam + BLOB_S);
+    const int t = threadIdx.x / LPP, part = threadIdx.x & (LPP - 1);
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const int i = (p < n) ? qorder[p] : 0;
+        stage<1>(img, lgam, tile, p1, gam, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        const double* sp = reinterpret_cast<const double*>(&p1[i]);
+        const Q4 s0 = gload4(sp), s1 = gload4(sp + 4);
+        __syncthreads();
+        if (p < n) {
+            const bool gas_i = s1.c > 0.0;
+            L1Acc a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int nm = KPAD(k) / LPP;
+            for (int m0 = 0; m0 < nm; ++m0) {
+                const int kk = LPP * m0 + part;
+                const unsigned sl = tile[kk * BLOB_P + t];
+                if (sl == SLOT_NONE) continue;
+                Q4 q0, q1;
+                double gj;
+                int j = -1;
+                if (sl < SLOT_OVER) { q0 = lload4(img, (int)sl, 0); q1 = lload4(img, (int)sl, 1); gj = lgam[sl]; }
+                else {
+                    j = nbr[(size_t)kk * npad + p];
+                    const double* q = reinterpret_cast<const double*>(&p1[j]);
+                    q0 = gload4(q); q1 = gload4(q + 4); gj = gam[j];
+                }
+                double dm = -1.0, dh = 0.0;
+                if (!(q1.c > 0.0)) {                           // not gas: dust needs its mass and size
+                    if (j < 0) j = nbr[(size_t)kk * npad + p];
+                    if (pt[j] == 2.0) { dm = m[j]; dh = h[j]; }
+                }
+                loop1_term(a, q0, q1, gj, dm, dh, s0.a, s0.b, s0.c, s1.d, gas_i, d9);
+            }
+            const double s_rho = group_total(a.rho), s_rd = group_total(a.rd), s_n = group_total(a.n);
+            const double gx = group_total(a.gx), gy = group_total(a.gy), gz = group_total(a.gz);
+            if (part == 0) {
+                rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+                G[3 * (size_t)i] = gx; G[3 * (size_t)i + 1] = gy; G[3 * (size_t)i + 2] = gz;
+                p2[i].rho = s_rho;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop2_kernel(int n, int npad, int k, int nblk,
+                                                                          const int* __restrict__ nbr,
+                                                                          const u16* __restrict__ slot16,
+                                                                          const int* __restrict__ uniq,
+                                                                          const int* __restrict__ qorder,
+                                                                          const RecP1* __restrict__ p1,
+                                                                          const RecP2* __restrict__ p2,
+                                                                          const double* __restrict__ m,
+                                                                          const double* __restrict__ h, double* va,
+                                                                          double* vh, u64* ct_bits) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, m, slot tile
+    __shared__ u64 sm[PASS_T / 64];
+    double* lm = reinterpret_cast<double*>(img + 4 * BLOB_S);
+    u16* tile = reinterpret_cast<u16*>(lm + BLOB_S);
+    const int t = threadIdx.x / LPP, part = threadIdx.x & (LPP - 1);
+    u64 mine = 0x7FF0000000000000ull;
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const int i = (p < n) ? qorder[p] : 0;
+        stage<1>(img, lm, tile, p2, m, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        const double* sp = reinterpret_cast<const double*>(&p2[i]);
+        const Q4 s0 = gload4(sp), sv = gload4(sp + 4);
+        const double hq_i = p1[i].hq, g1_i = p1[i].g1, m_i = m[i], h_i = h[i];
+        __syncthreads();
+        if (p < n) {
+            L2Acc a{0.0, 0.0, 0.0, 0.0};
+            double mx = 0.0;
+            if (s0.d >= 0.0) {
+                const int nm = KPAD(k) / LPP;
+                for (int m0 = 0; m0 < nm; ++m0) {
+                    const int kk = LPP * m0 + part;
+                    const unsigned sl = tile[kk * BLOB_P + t];
+                    if (sl == SLOT_NONE) continue;
+                    Q4 q0, qv;
+                    double mj;
+                    if (sl < SLOT_OVER) { q0 = lload4(img, (int)sl, 0); qv = lload4(img, (int)sl, 1); mj = lm[sl]; }
+                    else {
+                        const int j = nbr[(size_t)kk * npad + p];
+                        const double* q = reinterpret_cast<const double*>(&p2[j]);
+                        q0 = gload4(q); qv = gload4(q + 4); mj = m[j];
+                    }
+                    mx = fmax(mx, loop2_term(a, q0, qv, mj, s0, sv, sv.d, m_i, hq_i, g1_i));
+                }
+            }
+            const double ax = group_total(a.ax), ay = group_total(a.ay), az = group_total(a.az), heat = group_total(a.heat);
+            mx = group_max(mx);
+            if (part == 0) {
+                va[3 * (size_t)i] = ax; va[3 * (size_t)i + 1] = ay; va[3 * (size_t)i + 2] = az;
+                vh[i] = heat;
+                if (s0.d >= 0.0) {
+                    const double ct = nan_to_num_d(h_i / sqrt(mx));
+                    if (ct > 0.0) { const u64 cb = (u64)__double_as_longlong(ct); mine = cb < mine ? cb : mine; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 q = __shfl_xor(mine, o, 64);
+        mine = q < mine ? q : mine;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 r = sm[0];
+        for (int w = 1; w < PASS_T / 64; ++w) r = sm[w] < r ? sm[w] : r;
         if (r != 0x7FF0000000000000ull) atomicMin(ct_bits, r);
     }
 }
@@ -556,29 +721,49 @@ int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
     for (DevBuf* b : outs1) SPHX_TRY(sphx_ensure(ctx, *b, nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->va, 3 * nb));
-    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_a, (size_t)n * sizeof(RecLA)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_v, (size_t)n * sizeof(RecLV)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_b, (size_t)n * sizeof(RecLB)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_r, (size_t)n * sizeof(RecLR)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_a, (size_t)n * sizeof(RecP1)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->lrec_v, (size_t)n * sizeof(RecP2)));
     const unsigned grid = (unsigned)((n + 255) / 256);
     LoopPrepArgs p;
     p.n = (int)n;
     p.x = st.x.as<double>(); p.y = st.y.as<double>(); p.z = st.z.as<double>();
     p.vx = st.vx.as<double>(); p.vy = st.vy.as<double>(); p.vz = st.vz.as<double>();
-    p.m = st.m.as<double>(); p.pt = st.ptype.as<double>(); p.h = st.hprev.as<double>();
+    p.m = st.m.as<double>(); p.pt = st.ptype.as<double>();
     p.mu = st.mu.as<double>(); p.gam = st.gam.as<double>(); p.E = st.E.as<double>(); p.T = st.T.as<double>();
     p.d = d; p.m0 = ctx->cst.m_0; p.m_h = ctx->cst.m_h; p.kB = ctx->cst.k_B; p.amu = ctx->cst.amu;
-    p.la = ctx->lrec_a.as<RecLA>(); p.lb = ctx->lrec_b.as<RecLB>(); p.lv = ctx->lrec_v.as<RecLV>();
+    p.p1 = ctx->lrec_a.as<RecP1>(); p.p2 = ctx->lrec_v.as<RecP2>();
     hipLaunchKernelGGL(loop_prep_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
     const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
-    hipLaunchKernelGGL(loop_pass1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k, d9,
-                       ctx->nbr.as<int>(), p.la, p.lb, ctx->qorder, ctx->rho.as<double>(), ctx->rhod.as<double>(),
-                       ctx->nden.as<double>(), ctx->G.as<double>(), ctx->lrec_r.as<RecLR>());
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));       // 0x7F7F.. = huge finite "none yet"
-    hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, (int)sphx_pad64(n), k,
-                       ctx->nbr.as<int>(), p.la, p.lv, ctx->lrec_r.as<RecLR>(), st.hprev.as<double>(), ctx->qorder,
-                       ctx->va.as<double>(), ctx->vh.as<double>(), ct);
+    const int npad = (int)sphx_pad64(n);
+    if (ctx->qorder && ctx->blob_lists) {
+        if (!ctx->loop_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop1_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+            ctx->loop_attr_set = true;
+        }
+        const int nblk = (npad + BLOB_P - 1) / BLOB_P;
+        const int g = sphx_blob_grid(ctx, nblk);
+        hipLaunchKernelGGL(blob_loop1_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
+                           d9, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p.p1,
+                           st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(), st.hprev.as<double>(),
+                           ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(),
+                           p.p2);
+        hipLaunchKernelGGL(blob_loop2_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
+                           ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p.p1, p.p2,
+                           st.m.as<double>(), st.hprev.as<double>(), ctx->va.as<double>(), ctx->vh.as<double>(), ct);
+    } else {
+        hipLaunchKernelGGL(loop_pass1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, npad, k, d9,
+                           ctx->nbr.as<int>(), p.p1, st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(),
+                           st.hprev.as<double>(), ctx->qorder, ctx->rho.as<double>(), ctx->rhod.as<double>(),
+                           ctx->nden.as<double>(), ctx->G.as<double>(), p.p2);
+        hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, npad, k, ctx->nbr.as<int>(),
+                           p.p1, p.p2, st.m.as<double>(), st.hprev.as<double>(), ctx->qorder, ctx->va.as<double>(),
+                           ctx->vh.as<double>(), ct);
+    }
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -415,6 +415,29 @@ def test_step_loop_variants_are_bit_identical(workload, n, K, monkeypatch):
             assert np.array_equal(res["lds"][key], res[name][key]), (name, key)
 
 
+def test_loop_form_step_variants_are_bit_identical(monkeypatch):
+    """Loop-form mode: LDS passes (default), LDS with a squeezed image (global-memory fallback for part of the
+    references), gather passes in blob order, gather passes in storage order - one answer, bit for bit."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    s0 = ics.dusty_sphere(9000)
+    d = 3.0e18
+    res = {}
+    for name, env in (("lds", {}), ("lds_overflow", {"SPHX_BLOB_SLOTS": "300"}), ("blob_gather", {"SPHX_LDS": "0"}),
+                      ("storage_order", {"SPHX_BLOB": "0"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        sim = Simulation(s0, n_neigh=40, forms="loop", d=d)
+        sim.step(4)
+        res[name] = sim.download()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for name in ("lds_overflow", "blob_gather", "storage_order"):
+        for key in ("points", "velocities", "E_internal", "T", "sizes", "densities", "num_densities", "total_accel"):
+            assert np.array_equal(res["lds"][key], res[name][key]), (name, key)
+    assert np.any(res["lds"]["total_accel"] != 0.0)
+
+
 def test_snapshot_restart_is_bit_identical(tmp_path):
     """A run resumed from a snapshot continues exactly like the uninterrupted one."""
     import sph_code_amd.ics as ics
