@@ -610,25 +610,41 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
             const bool gas_i = s1.c > 0.0;
             L1Acc a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             const int nm = KPAD(k) / LPP;
-            for (int m0 = 0; m0 < nm; ++m0) {
-                const int kk = LPP * m0 + part;
-                const unsigned sl = tile[kk * BLOB_P + t];
-                if (sl == SLOT_NONE) continue;
-                Q4 q0, q1;
-                double gj;
-                int j = -1;
-                if (sl < SLOT_OVER) { q0 = lload4(img, (int)sl, 0); q1 = lload4(img, (int)sl, 1); gj = lgam[sl]; }
-                else {
-                    j = nbr[(size_t)kk * npad + p];
-                    const double* q = reinterpret_cast<const double*>(&p1[j]);
-                    q0 = gload4(q); q1 = gload4(q + 4); gj = gam[j];
+            for (int m0 = 0; m0 < nm; m0 += NB) {
+                unsigned sl[NB];
+                load_slots(sl, tile, m0, part, t);
+                Q4 q0b[NB], q1b[NB];
+                double gb[NB];
+                int jb[NB];
+                if (all_staged(sl)) {                          // the usual case: straight-line LDS reads
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        q0b[u] = lload4(img, (int)sl[u], 0); q1b[u] = lload4(img, (int)sl[u], 1); gb[u] = lgam[sl[u]];
+                        jb[u] = -1;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        jb[u] = -1;
+                        if (sl[u] < SLOT_OVER) {
+                            q0b[u] = lload4(img, (int)sl[u], 0); q1b[u] = lload4(img, (int)sl[u], 1); gb[u] = lgam[sl[u]];
+                        } else if (sl[u] == SLOT_OVER) {
+                            jb[u] = nbr[(size_t)(LPP * (m0 + u) + part) * npad + p];
+                            const double* q = reinterpret_cast<const double*>(&p1[jb[u]]);
+                            q0b[u] = gload4(q); q1b[u] = gload4(q + 4); gb[u] = gam[jb[u]];
+                        } else { q0b[u] = s0; q1b[u] = s1; gb[u] = 1.0; }
+                    }
                 }
-                double dm = -1.0, dh = 0.0;
-                if (!(q1.c > 0.0)) {                           // not gas: dust needs its mass and size
-                    if (j < 0) j = nbr[(size_t)kk * npad + p];
-                    if (pt[j] == 2.0) { dm = m[j]; dh = h[j]; }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (sl[u] == SLOT_NONE) continue;
+                    double dm = -1.0, dh = 0.0;
+                    if (!(q1b[u].c > 0.0)) {                   // not gas: dust needs its mass and size
+                        const int j = jb[u] >= 0 ? jb[u] : nbr[(size_t)(LPP * (m0 + u) + part) * npad + p];
+                        if (pt[j] == 2.0) { dm = m[j]; dh = h[j]; }
+                    }
+                    loop1_term(a, q0b[u], q1b[u], gb[u], dm, dh, s0.a, s0.b, s0.c, s1.d, gas_i, d9);
                 }
-                loop1_term(a, q0, q1, gj, dm, dh, s0.a, s0.b, s0.c, s1.d, gas_i, d9);
             }
             const double s_rho = group_total(a.rho), s_rd = group_total(a.rd), s_n = group_total(a.n);
             const double gx = group_total(a.gx), gy = group_total(a.gy), gz = group_total(a.gz);
@@ -672,19 +688,33 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop2_kernel(int n,
             double mx = 0.0;
             if (s0.d >= 0.0) {
                 const int nm = KPAD(k) / LPP;
-                for (int m0 = 0; m0 < nm; ++m0) {
-                    const int kk = LPP * m0 + part;
-                    const unsigned sl = tile[kk * BLOB_P + t];
-                    if (sl == SLOT_NONE) continue;
-                    Q4 q0, qv;
-                    double mj;
-                    if (sl < SLOT_OVER) { q0 = lload4(img, (int)sl, 0); qv = lload4(img, (int)sl, 1); mj = lm[sl]; }
-                    else {
-                        const int j = nbr[(size_t)kk * npad + p];
-                        const double* q = reinterpret_cast<const double*>(&p2[j]);
-                        q0 = gload4(q); qv = gload4(q + 4); mj = m[j];
+                for (int m0 = 0; m0 < nm; m0 += NB) {
+                    unsigned sl[NB];
+                    load_slots(sl, tile, m0, part, t);
+                    Q4 q0b[NB], qvb[NB];
+                    double mb[NB];
+                    if (all_staged(sl)) {
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1); mb[u] = lm[sl[u]];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            if (sl[u] < SLOT_OVER) {
+                                q0b[u] = lload4(img, (int)sl[u], 0); qvb[u] = lload4(img, (int)sl[u], 1); mb[u] = lm[sl[u]];
+                            } else if (sl[u] == SLOT_OVER) {
+                                const int j = nbr[(size_t)(LPP * (m0 + u) + part) * npad + p];
+                                const double* q = reinterpret_cast<const double*>(&p2[j]);
+                                q0b[u] = gload4(q); qvb[u] = gload4(q + 4); mb[u] = m[j];
+                            } else { q0b[u] = s0; qvb[u] = sv; mb[u] = m_i; }
+                        }
                     }
-                    mx = fmax(mx, loop2_term(a, q0, qv, mj, s0, sv, sv.d, m_i, hq_i, g1_i));
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        if (sl[u] == SLOT_NONE) continue;
+                        mx = fmax(mx, loop2_term(a, q0b[u], qvb[u], mb[u], s0, sv, sv.d, m_i, hq_i, g1_i));
+                    }
                 }
             }
             const double ax = group_total(a.ax), ay = group_total(a.ay), az = group_total(a.az), heat = group_total(a.heat);
