@@ -270,7 +270,7 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         cell = ctx->cell_factor * cbrt(V * (double)k / ((double)n * 4.1887902047863905));
     }
     if (cell < Lmax * 1e-4) cell = Lmax * 1e-4;
-    int64_t cap = 8 * n + 1024;
+    int64_t cap = 32 * n + 1024;      // cells per particle the grid may use when a diffuse halo stretches the box
     if (cap > SPHX_MAX_CELLS) cap = SPHX_MAX_CELLS;
     int nx, ny, nz;
     for (;;) {
