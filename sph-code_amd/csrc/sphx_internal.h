@@ -129,6 +129,7 @@ struct sphx_ctx {
     const double* tbox = nullptr;   // device: TRUE bounding box {min xyz, max xyz} of the last grid build
     double clip_lo[3] = {0, 0, 0}, clip_hi[3] = {0, 0, 0};   // statistics window of the robust grid box
     bool clip_valid = false;
+    double box_sigmas = 3.0;        // the grid covers mean +- this many standard deviations of the positions (SPHX_BOX_SIGMAS)
     double h_clip = 0.0;            // h above this is left out of the mean that sizes the cells (0: none)
     DevBuf cell_of, cell_start, cell_fill, perm, inv, scan_tmp, bbox_tmp;
     // ---- host-API staging ----
