@@ -63,7 +63,8 @@ __device__ __forceinline__ void sort_staged(const u64* skey, const u32* sid, int
     if (ABL == 1) return;              // timing experiment: no ordering network
     // degenerate radius (0 or overflowed): every key lands in bin 0 and the exact odd-even
     // fix-up below does all the ordering (slow, correct, practically never taken)
-    const double qscale = (r2 > 0.0 && r2 < 1e300) ? 67108862.0 / r2 : 0.0;
+    // (any positive scale orders correctly - ties are repaired below - so the hardware reciprocal will do)
+    const double qscale = (r2 > 0.0 && r2 < 1e300) ? 67108862.0 * __builtin_amdgcn_rcp(r2) : 0.0;
     const double qd = fmin(__longlong_as_double((long long)ck) * qscale, 67108862.0);
     u32 k32 = (lane < cnt) ? (((u32)qd << 6) | (u32)lane) : 0xFFFFFFFFu;
     sort32_sizes<64>(k32, lane);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             const int cz1 = (int)fminf(fmaxf(fz + Rc, 0.0f), nz1);
             const int ysp = cy1 - cy0 + 1;
             const int nrows = ysp * (cz1 - cz0 + 1);
-            const float inv_ysp = 1.0f / (float)ysp;
+            const float inv_ysp = __builtin_amdgcn_rcpf((float)ysp);
             const float Rc2 = Rc * Rc;
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
             bool have_best = false;           // best[] still empty: first flush is a plain sort
@@ -227,8 +228,12 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 const int r = rb + lane;
                 int s_row = 0, cnt = 0;
                 if (r < nrows) {
-                    const int rz = (nrows <= 65536) ? (int)(((float)r + 0.5f) * inv_ysp) : r / ysp;
-                    const int cy = cy0 + (r - rz * ysp), cz = cz0 + rz;
+                    // r / ysp: fp32 estimate (r < 2^24 rows, quotient <= 4096: off by one at most) + fix-up
+                    int rz = (int)(((float)r + 0.5f) * inv_ysp);
+                    int ry = r - rz * ysp;
+                    if (ry < 0) { --rz; ry += ysp; }
+                    if (ry >= ysp) { ++rz; ry -= ysp; }
+                    const int cy = cy0 + ry, cz = cz0 + rz;
                     // distance (in cells) from the query to the row's (y,z) cell column.  Boundary cells
                     // are half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
                     const float cyf = (float)cy, czf = (float)cz;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     dz = fmaxf(dz - 1e-3f, 0.0f);
                     const float rem = Rc2 - (dy * dy + dz * dz);
                     if (rem >= 0.0f) {        // the row meets the sphere: chord along x
-                        const float hc = sqrtf(rem) * 1.00001f + 1e-3f;
+                        const float hc = __builtin_amdgcn_sqrtf(rem) * 1.00001f + 1e-3f;   // 1 ulp: inside the padding
                         const int rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
                         const int rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
                         const int row = (cz * g.ny + cy) * g.nx;
@@ -249,12 +254,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                         cnt = a.cell_start[row + rx1 + 1] - s_row;
                     }
                 }
-                int incl = cnt;               // inclusive wave scan: incl[r] = first slot of row r+1
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    int up = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += up;
-                }
+                const int incl = wave_scan_incl(cnt);   // incl[r] = first slot of row r+1
                 const int sb = s_row - (incl - cnt);      // candidate slot t of row r is particle sb[r] + t
                 const int T = __builtin_amdgcn_readlane(incl, 63);
                 ncand += (u64)T;

@@ -122,6 +122,18 @@ template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lan
 }
 
 
+// inclusive wave64 prefix sum in six DPP adds: row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (out-of-row sources read 0)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // broadcast lane `src` (wave-uniform) of a double / int to the whole wave through SGPRs
 __device__ __forceinline__ double bcast_f64(double v, int src) {
     const long long b = __double_as_longlong(v);
