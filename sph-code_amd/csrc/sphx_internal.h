@@ -78,7 +78,7 @@ struct sphx_ctx {
     bool knn_hint_by_id = false;        // device API: search-radius hints are in caller order
     char err[512] = {0};
     sphx_constants cst;
-    double rscale = 1.12, cell_factor = 0.6;    // search tuning (sphx_set_tuning)
+    double rscale = 1.08, cell_factor = 0.55;    // search tuning (sphx_set_tuning)
     sphx_stats stats;
 
     // ---- working set (any particle order) ----

@@ -73,7 +73,7 @@ __device__ __forceinline__ void sort_staged(const u64* skey, const u32* sid, int
     ck = v ? skey[slot] : KNN_INF;
     cv = v ? sid[slot] : 0xFFFFFFFFu;
     const u32 nextq = (u32)__shfl_down((int)(k32 >> 6), 1, 64);
-    if (__ballot(v && lane < 63 && nextq == (k32 >> 6))) {
+    if (__builtin_amdgcn_ballot_w64(v && lane < 63 && nextq == (k32 >> 6))) {
         // same-bin neighbours: odd-even transposition on the exact keys until ordered
         for (int it = 0; it < 64; ++it) {
             u64 k0 = ck; u32 v0 = cv;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void sort_staged(const u64* skey, const u32* sid, int
                 const bool keep_min = (lane & 1) != 0;                  // the odd lane is the lower of its pair
                 if (p_lt == keep_min) { ck = pk; cv = pv; }
             }
-            if (!__ballot(k0 != ck || v0 != cv)) break;
+            if (!__builtin_amdgcn_ballot_w64(k0 != ck || v0 != cv)) break;
         }
     }
 }
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 const bool use_flags = (T <= KNN_FLAG_CAP);
                 const bool ne = cnt > 0;
                 if (use_flags) {
-                    const u64 nem = __ballot(ne);
+                    const u64 nem = __builtin_amdgcn_ballot_w64(ne);
                     if (ne) {
-                        rbase[__popcll(nem & ((1ull << lane) - 1ull))] = sb;
+                        rbase[lanes_below(nem)] = sb;
                         rflag[off] = 1;
                     }
                     wave_sync();
@@ -281,8 +281,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     const int tt = valid ? t : 0;
                     int p;
                     if (use_flags) {
-                        const u64 M = __ballot(valid && rflag[tt] != 0);
-                        const int ord = carry + __popcll(M & ((2ull << lane) - 1ull)) - 1;
+                        const bool starts = valid && rflag[tt] != 0;
+                        const u64 M = __builtin_amdgcn_ballot_w64(starts);
+                        const int ord = carry + lanes_below(M) - (starts ? 0 : 1);
                         carry += __popcll(M);
                         p = rbase[valid ? ord : 0] + tt;
                     } else {
@@ -295,18 +296,22 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                         }
                         p = __shfl(sb, rr, 64) + tt;
                     }
-                    const double d2 = dist2_nofma(a.x[p] - xi, a.y[p] - yi, a.z[p] - zi);
+                    // 32-bit byte offsets (n <= 2^29, checked by the launcher): scalar base + one VGPR
+                    const u32 boff = (u32)p << 3;
+                    const double d2 = dist2_nofma(*(const double*)((const char*)a.x + boff) - xi,
+                                                  *(const double*)((const char*)a.y + boff) - yi,
+                                                  *(const double*)((const char*)a.z + boff) - zi);
                     const u64 key = (u64)__double_as_longlong(d2);
                     // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass.
                     // ties in d2 are broken by the candidate's position in the cell-sorted order,
                     // which sphx_grid.hip makes deterministic (cells sorted by previous index)
                     const u32 pid = (u32)p;
                     const bool keep = valid && kv_less(key, pid, tk, tv);
-                    const u64 mask = __ballot(keep);
+                    const u64 mask = __builtin_amdgcn_ballot_w64(keep);
                     const int c = __popcll(mask);
                     if (c && ABL != 4) {
                         if (keep) {
-                            int pos = (head + nst + __popcll(mask & ((1ull << lane) - 1ull))) & 127;
+                            int pos = (head + nst + lanes_below(mask)) & 127;
                             skey[pos] = key;
                             sid[pos] = pid;
                         }
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
 
         // ---- outputs: lanes 0..K-1 hold the neighbours in ascending (d2, id) order ----
         const bool valid = (lane < K) && (bk != KNN_INF);
-        const int found = __popcll(__ballot(valid));
+        const int found = __popcll(__builtin_amdgcn_ballot_w64(valid));
         const double d = valid ? sqrt(__longlong_as_double((long long)bk)) : 0.0;
         const double dlast = __shfl(d, found > 0 ? found - 1 : 0, 64);
         const double hval = found > 0 ? dlast : 0.0;
@@ -415,7 +420,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
              const double* zs, const int32_t* id, const int32_t* inv, const double* rsearch,
              double rscale, double rbound, const KnnOut& out) {
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d not in 1..%d", k, SPHX_MAX_K);
-    if (n < 1 || n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
+    if (n < 1 || n > (1ll << 29)) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range (1..2^29)", (long long)n);
     KnnArgs a;
     a.n = (int)n;
     a.k = k;

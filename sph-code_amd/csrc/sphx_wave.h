@@ -122,6 +122,11 @@ template <int SIZE> __device__ __forceinline__ void sort32_sizes(u32& k, int lan
 }
 
 
+// number of set bits of a wave mask below this lane (v_mbcnt pair: no lane-mask registers)
+__device__ __forceinline__ int lanes_below(u64 m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
 // inclusive wave64 prefix sum in six DPP adds: row_shr 1/2/4/8 inside each row of 16 lanes, then
 // row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (out-of-row sources read 0)
 __device__ __forceinline__ int wave_scan_incl(int v) {
