@@ -291,6 +291,7 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     g.cell = cell; g.inv_cell = 1.0 / cell;
     g.nx = nx; g.ny = ny; g.nz = nz;
     g.ncells = nx * ny * nz;
+    g.fnx1 = (float)(nx - 1); g.fny1 = (float)(ny - 1); g.fnz1 = (float)(nz - 1);
     ctx->stats.cells = g.ncells;
     ctx->stats.cell_size = cell;
 

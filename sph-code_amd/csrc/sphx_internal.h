@@ -56,6 +56,7 @@ struct GridParams {
     double cell, inv_cell;
     int nx, ny, nz;
     int ncells;
+    float fnx1, fny1, fnz1;       // (float)(nx - 1) ...: kernel arguments cost no VALU conversions
 };
 
 // device-resident particle state, structure of arrays (one set; `alt` is the permute target)

@@ -197,11 +197,11 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         do {
             bk = KNN_INF;
             bv = 0xFFFFFFFFu;
-            // threshold: accept (key,id) < (tk,tv).  Inside the trial radius R the test is
-            // d2 <= R^2; at the caller's bound it is the strict d < dist of cKDTree.
+            // threshold: accept key < tk.  Inside the trial radius R the test is d2 <= R^2; at the
+            // caller's bound it is the strict d < dist of cKDTree; later the running K-th best, ties
+            // with it included (a superset: the merge orders by (key, index) and drops the excess).
             const bool at_bound = (R >= a.rbound);
-            u64 tk = (u64)__double_as_longlong(R * R);
-            u32 tv = at_bound ? 0u : 0xFFFFFFFFu;
+            u64 tk = (u64)__double_as_longlong(R * R) + (at_bound ? 0ull : 1ull);
             const double R2 = R * R;
             // Query position and radius in CELL units: fp64 once, then all range geometry in fp32.
             // Every fp32 quantity is padded (radius x(1+1e-5) + 2e-3 cells, distances - 1e-3 cells;
@@ -211,13 +211,16 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             const float fy = (float)((yi - g.ymin) * g.inv_cell);
             const float fz = (float)((zi - g.zmin) * g.inv_cell);
             const float Rc = (float)(R * g.inv_cell) * 1.00001f + 2e-3f;
-            const float nx1 = (float)(g.nx - 1), ny1 = (float)(g.ny - 1), nz1 = (float)(g.nz - 1);
+            const float nx1 = g.fnx1, ny1 = g.fny1, nz1 = g.fnz1;
+            // rows are tested against the query clamped into the grid: with it the half-infinite
+            // boundary cells need no special case (their open side can only lie behind the query)
+            const float fyc = fminf(fmaxf(fy, 0.0f), ny1 + 1.0f), fzc = fminf(fmaxf(fz, 0.0f), nz1 + 1.0f);
             const int cy0 = (int)fminf(fmaxf(fy - Rc, 0.0f), ny1);
             const int cy1 = (int)fminf(fmaxf(fy + Rc, 0.0f), ny1);
             const int cz0 = (int)fminf(fmaxf(fz - Rc, 0.0f), nz1);
             const int cz1 = (int)fminf(fmaxf(fz + Rc, 0.0f), nz1);
             const int ysp = cy1 - cy0 + 1;
-            const int nrows = ysp * (cz1 - cz0 + 1);
+            const int nrows = __mul24(ysp, cz1 - cz0 + 1);
             const float inv_ysp = __builtin_amdgcn_rcpf((float)ysp);
             const float Rc2 = Rc * Rc;
             int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
@@ -230,28 +233,25 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                 if (r < nrows) {
                     // r / ysp: fp32 estimate (r < 2^24 rows, quotient <= 4096: off by one at most) + fix-up
                     int rz = (int)(((float)r + 0.5f) * inv_ysp);
-                    int ry = r - rz * ysp;
+                    int ry = r - __mul24(rz, ysp);
                     if (ry < 0) { --rz; ry += ysp; }
                     if (ry >= ysp) { ++rz; ry -= ysp; }
                     const int cy = cy0 + ry, cz = cz0 + rz;
                     // distance (in cells) from the query to the row's (y,z) cell column.  Boundary cells
                     // are half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
                     const float cyf = (float)cy, czf = (float)cz;
-                    float dy = 0.0f, dz = 0.0f;
-                    if (cy > 0) dy = fmaxf(dy, cyf - fy);
-                    if (cy < g.ny - 1) dy = fmaxf(dy, fy - (cyf + 1.0f));
-                    if (cz > 0) dz = fmaxf(dz, czf - fz);
-                    if (cz < g.nz - 1) dz = fmaxf(dz, fz - (czf + 1.0f));
-                    dy = fmaxf(dy - 1e-3f, 0.0f);
-                    dz = fmaxf(dz - 1e-3f, 0.0f);
+                    const float dy = fmaxf(fmaxf(cyf - fyc, fyc - (cyf + 1.0f)) - 1e-3f, 0.0f);
+                    const float dz = fmaxf(fmaxf(czf - fzc, fzc - (czf + 1.0f)) - 1e-3f, 0.0f);
                     const float rem = Rc2 - (dy * dy + dz * dz);
                     if (rem >= 0.0f) {        // the row meets the sphere: chord along x
                         const float hc = __builtin_amdgcn_sqrtf(rem) * 1.00001f + 1e-3f;   // 1 ulp: inside the padding
                         const int rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
                         const int rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
-                        const int row = (cz * g.ny + cy) * g.nx;
-                        s_row = a.cell_start[row + rx0];
-                        cnt = a.cell_start[row + rx1 + 1] - s_row;
+                        // < 2^23 cells in all: 24-bit multiplies, 32-bit byte offsets
+                        const int row = __mul24(__mul24(cz, g.ny) + cy, g.nx);
+                        const char* cs = (const char*)a.cell_start;
+                        s_row = *(const int*)(cs + ((u32)(row + rx0) << 2));
+                        cnt = *(const int*)(cs + ((u32)(row + rx1 + 1) << 2)) - s_row;
                     }
                 }
                 const int incl = wave_scan_incl(cnt);   // incl[r] = first slot of row r+1
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     const int tt = valid ? t : 0;
                     int p;
                     if (use_flags) {
-                        const bool starts = valid && rflag[tt] != 0;
-                        const u64 M = __builtin_amdgcn_ballot_w64(starts);
-                        const int ord = carry + lanes_below(M) - (starts ? 0 : 1);
+                        const bool fl = rflag[tt] != 0;
+                        const u64 M = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(fl);
+                        const int ord = carry + lanes_below(M) - ((valid && fl) ? 0 : 1);
                         carry += __popcll(M);
                         p = rbase[valid ? ord : 0] + tt;
                     } else {
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     // ties in d2 are broken by the candidate's position in the cell-sorted order,
                     // which sphx_grid.hip makes deterministic (cells sorted by previous index)
                     const u32 pid = (u32)p;
-                    const bool keep = valid && kv_less(key, pid, tk, tv);
-                    const u64 mask = __builtin_amdgcn_ballot_w64(keep);
+                    const bool keep = valid && key < tk;
+                    const u64 mask = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(key < tk);
                     const int c = __popcll(mask);
                     if (c && ABL != 4) {
                         if (keep) {
@@ -331,9 +331,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                             }
                             // running threshold: the K-th best - or the 64th when the whole register
                             // set is kept as a Verlet list, which must then be exact to its last entry
-                            u64 kth = __shfl(bk, KT - 1, 64);
-                            u32 kthv = __shfl(bv, KT - 1, 64);
-                            if (kth != KNN_INF) { tk = kth; tv = kthv; }
+                            const u64 kth = __shfl(bk, KT - 1, 64);
+                            if (kth != KNN_INF) tk = kth + 1ull;
                         }
                     }
                 }
