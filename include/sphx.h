@@ -273,6 +273,11 @@ int sphx_dev_pack_rows(sphx_ctx* ctx, int64_t n, const int64_t* idx, int nf, con
 int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel, int64_t n_rows, const double* rows,
                      int nf, const double* const* fields_in, const int32_t* widths,
                      double* const* fields_out);
+/* multigpu.py DistributedSim._need_map: out (G^3 bytes, device) = 1 for every cell of the coarse grid
+ * (host array g_lo[3] = origin, g_cs = cubic cell edge) within floor(w_i/g_cs) + 1 cells of the cell of an
+ * owned particle i (pos (n,3), w (n): device) - the cells a neighbour of i can lie in.                 */
+int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
+                      double g_cs, int G, unsigned char* out);
 int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
                        double* E_internal, double* T, const double* mass, const double* mu,
                        const double* gamma, const double* ptype, const double* hydro_accel,

@@ -386,3 +386,48 @@ extern "C" int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
+
+// ---- need map of the decomposed driver (multigpu.py: DistributedSim._need_map) ----------------
+// out[c] = 1 for every cell c of a G^3 grid of cubic cells (origin g_lo, edge cs) that lies within
+// floor(w_i / cs) + 1 cells (Chebyshev) of the cell holding an owned particle i claiming reach w_i:
+// a superset of the cells from which a point can lie within w_i of particle i.  One thread per
+// particle writes its cube (27 bytes for nearly all; racing stores of the same value).
+__global__ __launch_bounds__(256) void need_map_kernel(long long n, const double* pos, const double* w, double lx,
+                                                       double ly, double lz, double cs, int G,
+                                                       unsigned char* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double wi = w[i];
+    if (!(wi > 0.0)) return;                       // claims nothing (NaN included)
+    const double g1 = (double)(G - 1);
+    // the particle's own cell: floor + clamp, as torch.floor(...).clamp_(0, G - 1) does
+    const double tx = fmin(fmax(floor((pos[3 * i] - lx) / cs), 0.0), g1);
+    const double ty = fmin(fmax(floor((pos[3 * i + 1] - ly) / cs), 0.0), g1);
+    const double tz = fmin(fmax(floor((pos[3 * i + 2] - lz) / cs), 0.0), g1);
+    const int cx = (tx == tx) ? (int)tx : 0, cy = (ty == ty) ? (int)ty : 0, cz = (tz == tz) ? (int)tz : 0;
+    const double rr = floor(wi / cs) + 1.0;
+    const int r = rr < (double)G ? (int)rr : G;
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            unsigned char* row = out + ((size_t)z * G + y) * G;
+            for (int x = x0; x <= x1; ++x) row[x] = 1;
+        }
+}
+
+extern "C" int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
+                                 double g_cs, int G, unsigned char* out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(g_lo); NEED(out);
+    if (n < 0 || G < 1 || G > 1024 || !(g_cs > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "need map: n=%lld G=%d cs=%g", (long long)n, G, g_cs);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(out, 0, (size_t)G * G * G, ctx->stream));
+    if (n == 0) return SPHX_OK;
+    NEED(pos); NEED(w);
+    hipLaunchKernelGGL(need_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, pos, w,
+                       g_lo[0], g_lo[1], g_lo[2], g_cs, G, out);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

@@ -106,7 +106,7 @@ class Exchanger:
         mine = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_device)
         allc = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine)
-        return [int(allc[p][self.rank]) for p in range(self.world)]
+        return torch.stack(allc)[:, self.rank].tolist()        # one device->host copy, not one per peer
 
     def rows(self, send_bufs, recv_counts, width, dtype=torch.float64, into=None):
         """send_bufs[p]: (count_p, width) tensor for peer p (any device) -> list of received
@@ -202,6 +202,15 @@ class LibBackend:
                                                 self._p(rows.contiguous()) if nr else None, len(fields), arr, wid, oarr))
         return outs
 
+    def need_map(self, pos, w, g_lo, g_cs, G):
+        """uint8 (G^3,) map of the coarse cells a neighbour of an owned particle can lie in (one launch;
+        include/sphx.h sphx_dev_need_map).  g_lo: 3 host floats."""
+        out = torch.empty(G * G * G, dtype=torch.uint8, device=self.device)
+        lo = (C.c_double * 3)(*g_lo)
+        self._chk(self.lib.sphx_dev_need_map(self.ctx.h, int(pos.shape[0]), self._p(pos.contiguous()),
+                                             self._p(w.contiguous()), lo, float(g_cs), int(G), self._p(out)))
+        return out
+
     def search(self, pos, n_owned, hint, mean_h):
         n = pos.shape[0]
         self.n_total = n
@@ -265,7 +274,7 @@ class DistributedSim:
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
     def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
-                 halo_scale=1.15, skin_frac=0.15, need_grid=96):
+                 halo_scale=1.15, skin_frac=0.15, need_grid=96, migrate_every=4):
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
@@ -286,6 +295,13 @@ class DistributedSim:
         self.w_plan, self.send_idx, self.recv_counts, self.pos_plan = None, None, None, None
         self.send_cat = None
         self.grow = 1.0
+        # strays are handed to their region's owner (and the owned arrays re-sorted) on every
+        # `migrate_every`-th replan: ownership is bookkeeping, the halo is built from where the owned
+        # particles ARE, so a particle a little outside its region's box costs nothing but reach
+        self.migrate_every = max(1, int(migrate_every))
+        # when the plan went stale on three steps running (large dt: some particle always moves more
+        # than the skin), the next steps replan without asking - two host-synchronising reductions less
+        self.stale_streak, self.force_replan = 0, 0
         # coarse global grid for the need maps: global bounding box of the initial state + 25 %
         pmin = self.s["pos"].min(dim=0).values if n else torch.full((3,), 1e300, dtype=torch.float64, device=self.device)
         pmax = self.s["pos"].max(dim=0).values if n else torch.full((3,), -1e300, dtype=torch.float64, device=self.device)
@@ -297,6 +313,7 @@ class DistributedSim:
         self.G = int(need_grid)
         self.g_lo = pmin - 0.25 * ext
         self.g_cs = float((1.5 * ext).max()) / self.G             # cubic coarse cells
+        self.g_lo_host = [float(v) for v in self.g_lo.tolist()]
         self.hmax_prev, self.hmean_prev = 0.0, 0.0
         self.last_ntotal = None
         self.first = True
@@ -339,6 +356,8 @@ class DistributedSim:
         """uint8 (G^3,): coarse cells from which a particle could lie within w_i of one of my owned
         particles.  Conservative: distances are under-estimated (Chebyshev cell distance - 1)."""
         G, cs = self.G, self.g_cs
+        if hasattr(self.backend, "need_map"):          # fused: one launch, no host synchronisation
+            return self.backend.need_map(self.s["pos"], w_owned, self.g_lo_host, cs, G)
         wmax = torch.zeros(G * G * G, dtype=torch.float64, device=self.device)
         if w_owned.numel():
             wmax.scatter_reduce_(0, self._coarse_cell(self.s["pos"]), w_owned, reduce="amax", include_self=True)
@@ -434,7 +453,9 @@ class DistributedSim:
     def _replan(self):
         """Migrate strays to their region's owner, then rebuild the send lists: every owned particle
         claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
-        self._reorder_and_migrate()
+        k_ = self.stats.get("replans", 0)
+        if k_ < 2 or k_ % self.migrate_every == 0:        # (the first two: one-off set-up costs paid early)
+            self._reorder_and_migrate()
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
         # (a radius changes by at most twice the local displacement, so fast movers claim more)
@@ -482,6 +503,10 @@ class DistributedSim:
                 s["h"] = be.search(s["pos"], no, None, 0.0)[:no].contiguous()
             self._replan()
             D = 0.0
+        elif self.force_replan > 0:
+            self.force_replan -= 1
+            self._replan()
+            D = 0.0
         else:
             if no:
                 d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
@@ -489,9 +514,14 @@ class DistributedSim:
                 d_loc = 0.0
             D = self._allreduce_max(d_loc)                    # bound on the displacement norm
             stale = float((self.halo_scale * s["h"] + 2.0 * D > self.w_plan).any()) if no else 0.0
-            if self._allreduce_max(stale) > 0.5:
+            if self._allreduce_max(stale) > 0.5:              # (the same verdict on every rank)
                 self._replan()
                 D = 0.0
+                self.stale_streak += 1
+                if self.stale_streak >= 3:
+                    self.stale_streak, self.force_replan = 0, 16
+            else:
+                self.stale_streak = 0
         while True:
             s, no = self.s, self.n_owned                      # (a replan may have migrated particles)
             send_idx, recv_counts = self.send_idx, self.recv_counts

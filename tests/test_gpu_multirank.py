@@ -124,3 +124,43 @@ def test_fused_row_kernels_match_tensor_forms():
             for x, y in zip(a, b):
                 assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
     torch.cuda.synchronize()
+
+
+def test_need_map_kernel_matches_tensor_form():
+    """sphx_dev_need_map (one launch, no host sync) gives the very map of the tensor-library form
+    (DistributedSim._need_map without a fused backend): owned particles inside, on the edge of and
+    outside the coarse grid, reaches from 0 to several cells to the whole grid."""
+    import torch
+    from sph_code_amd.multigpu import LibBackend, DistributedSim
+    be = LibBackend(0, k=8)
+    dev = be.device
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n, G = 5000, 24
+    pos = (torch.rand((n, 3), generator=g, dtype=torch.float64) * 1.4 - 0.2)      # some outside [0,1]^3
+    pos[:8] = torch.tensor([[0.0, 0.5, 1.0], [1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [-3.0, 0.2, 0.2],
+                            [0.25, 0.25, 0.25], [1.0 / 24, 2.0 / 24, 3.0 / 24], [0.999999, 0.0, 0.3], [2.0, 2.0, 2.0]],
+                           dtype=torch.float64)
+    w = torch.rand(n, generator=g, dtype=torch.float64) * 0.03
+    w[::97] = 0.0                        # claims nothing
+    w[5::211] = 0.2                      # several cells
+    w[7] = 1.0 / 24                      # exactly one cell edge
+    w[3] = 50.0                          # the whole grid
+
+    class Plain:
+        pass
+
+    def sim(backend, pos_, w_):
+        s_ = DistributedSim.__new__(DistributedSim)
+        s_.backend, s_.device, s_.G = backend, dev, G
+        s_.g_lo = torch.zeros(3, dtype=torch.float64, device=dev)
+        s_.g_lo_host = [0.0, 0.0, 0.0]
+        s_.g_cs = 1.0 / G
+        s_.s = dict(pos=pos_.to(dev))
+        return s_._need_map(w_.to(dev))
+
+    for sl in (slice(None), slice(8, None), slice(0, 3), slice(0, 0)):
+        a, b = sim(Plain(), pos[sl], w[sl]), sim(be, pos[sl], w[sl])
+        assert a.dtype == b.dtype == torch.uint8 and a.shape == b.shape
+        assert torch.equal(a, b), int((a != b).sum())
+    assert 0 < int(sim(be, pos[8:], w[8:]).sum()) < G ** 3      # a non-trivial map
+    torch.cuda.synchronize()

@@ -189,3 +189,17 @@ def test_world8_gloo_runs(tmp_path):
     np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-13)
     assert len(set(got["dt"])) == 1
+
+
+def test_world2_eight_steps_delayed_migration_and_forced_replans(tmp_path):
+    """Eight steps under the reference's large dt: the plan goes stale every step (after three in a
+    row the staleness reductions are skipped and every step replans), strays are handed over only on
+    every 4th replan - the result is still the single-domain one."""
+    n, nsteps = 2000, 8
+    got = _run_world(2, n, nsteps, "uniform_sphere", tmp_path)
+    ref = _reference(n, nsteps, "uniform_sphere")
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
+    ghosts, redo, migrated, sent, replans = got["stats"]
+    assert ghosts > 0 and replans >= nsteps and migrated > 0          # (summed over the ranks)
