@@ -22,28 +22,44 @@
 // distinct neighbours; the most seen at BLOB_P = 128 is ~800) keeps the 0xFFFE marker and is
 // fetched from global memory through the int32 list.
 #include "sphx_blob.h"
+#include "sphx_wave.h"
 #pragma clang fp contract(off)
 #include <float.h>
 #include <stdlib.h>
 #include <stdio.h>
 
 // ---- once per step: distinct neighbours of each workgroup ------------------------------------
+// Phase 1: every reference is inserted into a sparse open-addressing table of particle indices
+// (DD_TAB entries for <= ~900 distinct keys: 1.2 probes on average, where a table as small as the
+// image needed 3-4 and its slowest lane 15) and remembers the entry it landed in (LDS tile, 16 bit).
+// Phase 2: the occupied entries are numbered in table order by a workgroup prefix sum - the image
+// slots, dense from 0 - and written out as the slot -> particle table.  Phase 3: the tile is
+// translated entry -> slot in place and leaves as whole 256-B rows.  (The slot numbering depends on
+// which lane won an entry; no sum depends on it.)
+#define DD_TAB 2048
+#define DD_PROBES 64
+__device__ __forceinline__ unsigned dd_hash(int j) { return ((unsigned)j * 2654435761u) >> 21; }
+
 __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int k, int slots,
                                                             const int* __restrict__ nbr, u16* slot16,
                                                             int* uniq) {
-    __shared__ int tab[BLOB_S];
+    extern __shared__ u16 dd_tile[];              // [k][BLOB_P] entry / slot numbers
+    __shared__ int key[DD_TAB];
+    __shared__ u16 slot_of[DD_TAB];
+    __shared__ int wave_tot[BLOB_T / 64];
     const int b = xcd_block(blockIdx.x, gridDim.x);
     const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
     const int p = b * BLOB_P + t;
-    for (int q = threadIdx.x; q < BLOB_S; q += BLOB_T) tab[q] = (q < slots) ? -1 : -2;    // -2: closed
+    for (int q = threadIdx.x; q < DD_TAB; q += BLOB_T) key[q] = -1;
     __syncthreads();
-    if (p < npad) {
+    {
         const int nm = (k + 1) >> 1;
+        const bool live = p < n;
         int jn[DD_BATCH];                         // the next batch is in flight while this one is hashed
 #pragma unroll
         for (int u = 0; u < DD_BATCH; ++u) {
             const int kk = 2 * u + half;
-            jn[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
+            jn[u] = (kk < k && live) ? nbr[(size_t)kk * npad + p] : -1;
         }
         for (int m0 = 0; m0 < nm; m0 += DD_BATCH) {
             int jb[DD_BATCH];
@@ -51,7 +67,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
             for (int u = 0; u < DD_BATCH; ++u) {
                 jb[u] = jn[u];
                 const int kk = 2 * (m0 + DD_BATCH + u) + half;
-                jn[u] = (kk < k && p < n) ? nbr[(size_t)kk * npad + p] : -1;
+                jn[u] = (kk < k && live) ? nbr[(size_t)kk * npad + p] : -1;
             }
 #pragma unroll
             for (int u = 0; u < DD_BATCH; ++u) {
@@ -60,24 +76,67 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
                 const int j = jb[u];
                 unsigned s = SLOT_NONE;
                 if (j >= 0) {
-                    unsigned h = slot_hash(j);
+                    unsigned h = dd_hash(j);
                     s = SLOT_OVER;
-                    for (int probe = 0; probe < BLOB_PROBES; ++probe) {
-                        int e = tab[h];
+                    for (int probe = 0; probe < DD_PROBES; ++probe) {
+                        int e = key[h];
                         if (e == -1) {
-                            e = atomicCAS(&tab[h], -1, j);
+                            e = atomicCAS(&key[h], -1, j);
                             if (e == -1) e = j;
                         }
                         if (e == j) { s = h; break; }
-                        h = (h + 1 == BLOB_S) ? 0u : h + 1;
+                        h = (h + 1) & (DD_TAB - 1);
                     }
                 }
-                slot16[(size_t)kk * npad + p] = (u16)s;
+                dd_tile[kk * BLOB_P + t] = (u16)s;
             }
         }
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < BLOB_S; q += BLOB_T) uniq[(size_t)b * BLOB_S + q] = tab[q];
+    // number the occupied entries: DD_TAB / BLOB_T consecutive entries per thread
+    constexpr int EPT = DD_TAB / BLOB_T;
+    const int e0 = threadIdx.x * EPT;
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) cnt += key[e0 + q] != -1;
+    const int incl = wave_scan_incl(cnt);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int base = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOB_T / 64; ++w) {
+        const int tw = wave_tot[w];
+        if (w < wv) base += tw;
+        total += tw;
+    }
+    int* uq = uniq + (size_t)b * BLOB_S;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int j = key[e0 + q];
+        if (j != -1) {
+            slot_of[e0 + q] = (u16)(base < slots ? base : SLOT_OVER);
+            if (base < slots) uq[base] = j;
+            ++base;
+        }
+    }
+    for (int q = (total < slots ? total : slots) + threadIdx.x; q < BLOB_S; q += BLOB_T) uq[q] = -1;
+    __syncthreads();
+    // entry -> slot, then out in 16-B pieces of whole rows
+    const int pieces = k * (BLOB_P / 8);
+    for (int q = threadIdx.x; q < pieces; q += BLOB_T) {
+        u16* src = dd_tile + q * 8;
+        const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned e = src[u];
+            v[u] = e < DD_TAB ? (unsigned)slot_of[e] : e;
+        }
+        if ((size_t)b * BLOB_P + c * 8 < (size_t)npad)
+            *reinterpret_cast<uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8) =
+                make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
 }
 
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
@@ -88,7 +147,7 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
     int slots = ctx->blob_slots;
     if (slots < 1) slots = 1;
     if (slots > BLOB_S) slots = BLOB_S;
-    hipLaunchKernelGGL(blob_dedup_kernel, dim3(nblk), dim3(BLOB_T), 0, ctx->stream, (int)n, (int)npad, k, slots,
+    hipLaunchKernelGGL(blob_dedup_kernel, dim3(nblk), dim3(BLOB_T), (size_t)k * BLOB_P * sizeof(u16), ctx->stream, (int)n, (int)npad, k, slots,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>());
     HIPCHK(hipGetLastError());
     ctx->blob_lists = true;
