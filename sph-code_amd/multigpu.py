@@ -320,8 +320,27 @@ class DistributedSim:
         self.dt_last = 0.0
         self.last = {}
         self.stats = dict(steps=0, ghosts=0, redo=0, migrated=0)
+        self.host_ms = {}
 
     # ------------------------------------------------------------------------------------------
+    class _Section:
+        """Host wall time of a section of step(), accumulated in sim.host_ms[name].  No extra
+        synchronisation: GPU work is charged to the section whose host code next waits for it."""
+        __slots__ = ("acc", "name", "t")
+
+        def __init__(self, acc, name):
+            self.acc, self.name = acc, name
+
+        def __enter__(self):
+            self.t = time.perf_counter()
+
+        def __exit__(self, *exc):
+            self.acc[self.name] = self.acc.get(self.name, 0.0) + (time.perf_counter() - self.t) * 1e3
+            return False
+
+    def _sec(self, name):
+        return self._Section(self.host_ms, name)
+
     @property
     def n_owned(self):
         return self.s["pos"].shape[0]
@@ -501,21 +520,26 @@ class DistributedSim:
             # for the first exchange
             if no:
                 s["h"] = be.search(s["pos"], no, None, 0.0)[:no].contiguous()
-            self._replan()
+            with self._sec("replan"):
+                self._replan()
             D = 0.0
         elif self.force_replan > 0:
             self.force_replan -= 1
-            self._replan()
+            with self._sec("replan"):
+                self._replan()
             D = 0.0
         else:
-            if no:
-                d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
-            else:
-                d_loc = 0.0
-            D = self._allreduce_max(d_loc)                    # bound on the displacement norm
-            stale = float((self.halo_scale * s["h"] + 2.0 * D > self.w_plan).any()) if no else 0.0
-            if self._allreduce_max(stale) > 0.5:              # (the same verdict on every rank)
-                self._replan()
+            with self._sec("stale_check"):
+                if no:
+                    d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
+                else:
+                    d_loc = 0.0
+                D = self._allreduce_max(d_loc)                    # bound on the displacement norm
+                stale = float((self.halo_scale * s["h"] + 2.0 * D > self.w_plan).any()) if no else 0.0
+                is_stale = self._allreduce_max(stale) > 0.5       # (the same verdict on every rank)
+            if is_stale:
+                with self._sec("replan"):
+                    self._replan()
                 D = 0.0
                 self.stale_streak += 1
                 if self.stale_streak >= 3:
@@ -530,11 +554,14 @@ class DistributedSim:
             mean_h = self.hmean_prev
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
             state_fields = [s["pos"], s["vel"], s["m"], s["T"], s["mu"], s["gam"], s["ptype"], s["h"]]
-            g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
-            pos, vel, m, T, mu, gam, ptype, hint = self._regroup(None, no, g, state_fields)
-            h = be.search(pos, no, hint, mean_h)
-            bad = float((h[:no] + 2.0 * D > self.w_plan).any()) if no else 0.0
-            if self._allreduce_max(bad) < 0.5:
+            with self._sec("halo_state"):
+                g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
+                pos, vel, m, T, mu, gam, ptype, hint = self._regroup(None, no, g, state_fields)
+            with self._sec("search+reach_check"):
+                h = be.search(pos, no, hint, mean_h)
+                bad = float((h[:no] + 2.0 * D > self.w_plan).any()) if no else 0.0
+                ok = self._allreduce_max(bad) < 0.5
+            if ok:
                 break
             # a kNN radius outgrew its claimed reach somewhere: those particles claim their new radius
             # (x1.5) and everybody replans
@@ -547,15 +574,17 @@ class DistributedSim:
         # ---- halo phases 2-4: 8 B per ghost, received straight into the tail of the (n_total,)
         # array the library just filled for the owned particles --------------------------------
         tail = lambda a: a[no:].view(ng, 1)
-        self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)            # h_j
-        be.prep(pos, vel, m, h, T, mu, gam, ptype)
-        rho, nden, ha = be.density()
-        self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)        # rho_j
-        bw, ct = be.pi(rho)
-        self._exchange(send_idx, recv_counts, [bw[:no]], into=tail(bw), send_cat=self.send_cat)          # m Pi_j
-        va, vh = be.visc(bw, m)
+        with self._sec("sums+halo_scalars"):
+            self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)            # h_j
+            be.prep(pos, vel, m, h, T, mu, gam, ptype)
+            rho, nden, ha = be.density()
+            self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)        # rho_j
+            bw, ct = be.pi(rho)
+            self._exchange(send_idx, recv_counts, [bw[:no]], into=tail(bw), send_cat=self.send_cat)          # m Pi_j
+            va, vh = be.visc(bw, m)
         # ---- dt: global minimum crossing time (nsc:786, drv:222-229) ----------------------------
         # one host synchronisation for this step's scalars: crossing time, max and mean h
+        t_dt = time.perf_counter()
         if no:
             ctt = ct.reshape(-1)[:1].to(h.dtype) if torch.is_tensor(ct) else torch.tensor([float(ct)], dtype=h.dtype)
             ho = h[:no]
@@ -578,6 +607,7 @@ class DistributedSim:
                 dt = self.MAX_AGE / 100.
         be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
                      ha, va, vh, dt)
+        self.host_ms["dt+integrate"] = self.host_ms.get("dt+integrate", 0.0) + (time.perf_counter() - t_dt) * 1e3
         s["h"] = h[:no].contiguous()
         self.last = dict(rho=rho[:no], nden=nden[:no], visc_heat=vh[:no])
         self.dt_last = dt
@@ -683,7 +713,8 @@ def bench_main(args, rank, local_rank, world):
     for _ in range(args.warmup):
         sim.step()
     sim.ex.bytes_sent = 0
-    sim.stats.update(ghosts=0, redo=0, migrated=0)
+    sim.stats.update(ghosts=0, redo=0, migrated=0, replans=0)
+    sim.host_ms.clear()
     be.ctx.reset_stats()
     torch.cuda.synchronize()
     dist.barrier()
@@ -726,7 +757,12 @@ def bench_main(args, rank, local_rank, world):
                                         "kernel_ms": ms, "queries_per_launch": q})(
                 kst["ms_search"] / max(kst["steps"], 1), sim.n_owned) if kst["steps"] else None,
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
-                     "search_redos": float(cnt[3])},
+                     "search_redos": float(cnt[3]),
+                     "replans_per_step_rank0": sim.stats.get("replans", 0) / max(args.steps, 1),
+                     "migrated_rank0": sim.stats.get("migrated", 0)},
+            # rank 0's host wall time per step by section of DistributedSim.step (no added syncs: GPU
+            # work is charged to the section whose host code next waits for it)
+            "host_ms_per_step_rank0": {k_: v / max(args.steps, 1) for k_, v in sorted(sim.host_ms.items())},
             "step_model": {"algorithmic_bytes_per_particle_step": 1248,
                            "achieved_GBs": 1248 * value / 1e9,
                            "frac_of_hbm_peak": 1248 * value / 1e9 / (8000.0 * world)},
