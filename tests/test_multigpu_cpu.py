@@ -74,7 +74,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nsteps, workload, out_dir):
+def _worker(rank, world, port, n, nsteps, workload, out_dir, sim_kw=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -84,7 +84,7 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir):
     from sph_code_amd import multigpu as mg
     state = ics.WORKLOADS[workload](n, light=True)
     mine, lo, hi = mg.decompose_state(state, world, rank)
-    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu")
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **(sim_kw or {}))
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
@@ -95,9 +95,9 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir):
     dist.destroy_process_group()
 
 
-def _run_world(world, n, nsteps, workload, tmp_path):
+def _run_world(world, n, nsteps, workload, tmp_path, sim_kw=None):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, nsteps, workload, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, nsteps, workload, str(tmp_path), sim_kw), nprocs=world, join=True)
     parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
     gid = np.concatenate([p["gid"] for p in parts])
     assert np.array_equal(np.sort(gid), np.arange(n)), "particles lost or duplicated"
@@ -203,3 +203,18 @@ def test_world2_eight_steps_delayed_migration_and_forced_replans(tmp_path):
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
     ghosts, redo, migrated, sent, replans = got["stats"]
     assert ghosts > 0 and replans >= nsteps and migrated > 0          # (summed over the ranks)
+
+
+def test_world2_halo_too_thin_is_detected_and_redone(tmp_path):
+    """No head-room in the claimed reach (halo_scale 1, no skin): after the first move some kNN radius
+    outgrows its claim, which the end-of-step verdict (one reduction with dt) must catch - the step's
+    search and sums are redone with a wider halo and the result is still the single-domain one."""
+    n, nsteps = 2000, 3
+    got = _run_world(2, n, nsteps, "uniform_sphere", tmp_path, sim_kw=dict(halo_scale=1.0, skin_frac=0.0))
+    ref = _reference(n, nsteps, "uniform_sphere")
+    ghosts, redo, migrated, sent, replans = got["stats"]
+    assert redo > 0
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
+    assert got["dt"][0] == got["dt"][1] == pytest.approx(ref["dt"], rel=1e-14)
