@@ -14,15 +14,18 @@ design, following SURVEY.md 8(e):
     rho_j and m*Pi_j from their owners between the passes (the kernel uses the NEIGHBOUR's h
     (nsc:587-588), rho (nsc:646) and Pi (nsc:651)) - four point-to-point halo phases;
   * exchange = grouped isend/irecv between the (at most world-1) peers that share a halo, no
-    collective on the data path; the only collectives are two scalars per step (halo widths:
-    all_gather of one double; dt: all_reduce(min) of the crossing time, nsc:786);
+    collective on the data path; the collectives are the need maps and counts of a replan and
+    ONE scalar reduction per step (all_reduce(max) of [halo verdict, -crossing time]: dt is the
+    global minimum crossing time, nsc:786);
   * the send lists (the "plan") are reused from step to step with a skin, molecular-dynamics
-    style: they are rebuilt - and particles that left their region migrate to the new owner -
-    only when displacements since the last plan exceed half the skin.
+    style, while displacements since the last plan stay below half the skin; under the
+    reference's large dt they rarely do, so replanning is kept cheap (fused need-map kernel,
+    migration of strays only on every 4th replan, staleness checks skipped while every step
+    replans anyway).
 
-Halo coverage is verified after every search (h_i + 2 x displacement <= width for every owned
-particle, otherwise all ranks replan with a wider halo and redo the search), so the decomposed
-result equals the single-GPU result.
+Halo coverage is verified every step (h_i + 2 x displacement <= claimed reach for every owned
+particle, otherwise all ranks replan with a wider halo and redo the step's search and sums), so
+the decomposed result equals the single-GPU result.
 
 Compute is injected through a small backend interface; the product backend `LibBackend` calls
 libsphx.so's sphx_dev_* entry points on the rank's GPU (no CPU fallback).
