@@ -76,6 +76,11 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
     ctx->own_stream = ctx->stream;
     for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    for (int r = 0; ok && r < 3; ++r)
+        for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->evring[r][i]) == hipSuccess;
+    for (int r = 0; ok && r < 2; ++r)
+        ok = hipEventCreateWithFlags(&ctx->lag_bev[r], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->lag_hev[r], hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -117,6 +122,13 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     free_state(ctx->alt);
     for (int i = 0; i < 10; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int r = 0; r < 3; ++r)
+        for (int i = 0; i < 10; ++i)
+            if (ctx->evring[r][i]) (void)hipEventDestroy(ctx->evring[r][i]);
+    for (int r = 0; r < 2; ++r) {
+        if (ctx->lag_bev[r]) (void)hipEventDestroy(ctx->lag_bev[r]);
+        if (ctx->lag_hev[r]) (void)hipEventDestroy(ctx->lag_hev[r]);
+    }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -328,6 +340,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->list_valid = false;
     ctx->clip_valid = false;
     ctx->h_clip = 0.0;
+    ctx->lag_bvalid[0] = ctx->lag_bvalid[1] = ctx->lag_hvalid[0] = ctx->lag_hvalid[1] = false;
     ctx->step_count = 0;
     ctx->dt_last = 0.0;
     return SPHX_OK;
@@ -378,7 +391,8 @@ extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
 
 static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_dt) {
     const int64_t n = ctx->n;
-    hipEvent_t* ev = ctx->ev;
+    const int ring = (int)(ctx->step_count % 3);
+    hipEvent_t* ev = ctx->evring[ring];
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
@@ -405,10 +419,17 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         // cell size from the previous step's mean h (read back together with the bounding box)
         double cell_hint = 0.0;
         if (ctx->step_count > 0) {
-            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, 4 * sizeof(double),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            const double* hs = (const double*)((char*)ctx->pinned + 256);     // [0] sum ... [3] count
+            const double* hs;                                                  // [0] sum ... [3] count
+            if (ctx->lag_hvalid[ctx->lag_hslot]) {
+                // copied out right after the previous step's search: no wait on that step's tail
+                HIPCHK(hipEventSynchronize(ctx->lag_hev[ctx->lag_hslot]));
+                hs = (const double*)((char*)ctx->pinned + LAG_OFF + 512 * ctx->lag_hslot + 256);
+            } else {
+                HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, 4 * sizeof(double),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                hs = (const double*)((char*)ctx->pinned + 256);
+            }
             const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
             if (hmean > 0.0 && isfinite(hmean)) {
                 cell_hint = ctx->cell_factor * hmean;
@@ -416,8 +437,11 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             }
         }
         {
-            StateArrays& r = ctx->st;       // sphx_build_grid synchronises (bounding-box read-back)
-            SPHX_TRY(sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint));
+            StateArrays& r = ctx->st;       // the box statistics are the previous step's when there are any
+            ctx->lag_on = true;
+            const int rc_ = sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint);
+            ctx->lag_on = false;
+            SPHX_TRY(rc_);
         }
         SPHX_TRY(sphx_permute_state(ctx, n));
         if (ctx->use_blob && !ctx->use_verlet) SPHX_TRY(sphx_build_blob_order(ctx, n));
@@ -448,6 +472,14 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     StateArrays& s = ctx->st;
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
     SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
+    {   // the next step's cell size: out to the host now, read there when the next grid is sized
+        const int hsl = ctx->lag_hslot ^ 1;
+        HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
+                              4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->lag_hev[hsl], ctx->stream));
+        ctx->lag_hvalid[hsl] = true;
+        ctx->lag_hslot = hsl;
+    }
     // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side
     const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
     if (fork) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -515,8 +547,10 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     return SPHX_OK;
 }
 
-static int collect_stats(sphx_ctx* ctx) {
-    hipEvent_t* ev = ctx->ev;
+static int collect_stats(sphx_ctx* ctx, int ring) {
+    if (!(ctx->ev_pending & (1u << ring))) return SPHX_OK;
+    ctx->ev_pending &= ~(1u << ring);
+    hipEvent_t* ev = ctx->evring[ring];
     HIPCHK(hipEventSynchronize(ev[7]));
     float ms[7];
     for (int i = 0; i < 7; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
@@ -544,11 +578,15 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     if (!(dist > 0.0) || !isfinite(dist)) dist = 0.0;
     ctx->k = k;
     for (int it = 0; it < nsteps; ++it) {
+        const int ring = (int)(ctx->step_count % 3);
+        SPHX_TRY(collect_stats(ctx, ring));            // (the step launched three steps ago, if still uncollected)
         SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt));
-        SPHX_TRY(collect_stats(ctx));
+        ctx->ev_pending |= 1u << ring;
+        SPHX_TRY(collect_stats(ctx, (ring + 1) % 3));  // two steps ago: finished long since, no wait
     }
     HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->scal.p, SC_NSLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < 3; ++r) SPHX_TRY(collect_stats(ctx, (int)((ctx->step_count + r) % 3)));   // oldest first
     const u64* sc = (const u64*)ctx->pinned;
     ctx->dt_last = ((const double*)ctx->pinned)[SC_DT];
     ctx->stats.candidates = (int64_t)sc[SC_CAND];

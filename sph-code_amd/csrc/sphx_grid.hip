@@ -88,8 +88,9 @@ __global__ __launch_bounds__(64) void bbox_final(int nblocks, const double* part
 
 // out_minmax[0..5] = bounding box of all finite points; [6..8] mean, [9..11] standard deviation,
 // [12] count - the last three over the context's clip box when it is valid (use_clip)
-int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
-              double out_minmax[13], bool use_clip) {
+// launch the reduction over the current positions and its copy to `host_dst` (pinned); no wait
+static int bbox_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z, bool use_clip,
+                       void* host_dst) {
     ClipBox clip;
     clip.on = (use_clip && ctx->clip_valid) ? 1 : 0;
     for (int c = 0; c < 3; ++c) { clip.lo[c] = ctx->clip_lo[c]; clip.hi[c] = ctx->clip_hi[c]; }
@@ -101,9 +102,12 @@ int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, clip, part);
     hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(64), 0, ctx->stream, blocks, part, fin);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx->pinned, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(out_minmax, ctx->pinned, BB_W * sizeof(double));
+    HIPCHK(hipMemcpyAsync(host_dst, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return SPHX_OK;
+}
+// sums -> mean and standard deviation
+static void bbox_finish(const void* host_src, double out_minmax[13]) {
+    memcpy(out_minmax, host_src, BB_W * sizeof(double));
     const double cnt = out_minmax[12] > 0.0 ? out_minmax[12] : 1.0;
     for (int c = 0; c < 3; ++c) {
         const double mean = out_minmax[6 + c] / cnt;
@@ -111,6 +115,12 @@ int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
         out_minmax[6 + c] = mean;
         out_minmax[9 + c] = var > 0.0 ? sqrt(var) : 0.0;
     }
+}
+int sphx_bbox(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const double* z,
+              double out_minmax[13], bool use_clip) {
+    SPHX_TRY(bbox_launch(ctx, n, x, y, z, use_clip, ctx->pinned));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bbox_finish(ctx->pinned, out_minmax);
     return SPHX_OK;
 }
 
@@ -234,7 +244,25 @@ __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* 
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint) {
     double bb[13];
-    SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, true));
+    if (ctx->lag_on) {
+        // Fused step loop: this step's statistics are launched and copied out, the grid is sized from
+        // the previous step's (already on the host) - the loop never waits for the step it launches.
+        // One step of motion makes the box slightly stale, which only steers performance: particles
+        // outside it are clamped into the boundary cells.  (tbox, the device-side true bounding box
+        // the search reads, is this step's.)
+        const int prev = ctx->lag_bslot, cur = prev ^ 1;
+        char* slot = (char*)ctx->pinned + LAG_OFF;
+        SPHX_TRY(bbox_launch(ctx, n, x, y, z, true, slot + 512 * cur));
+        HIPCHK(hipEventRecord(ctx->lag_bev[cur], ctx->stream));
+        const int use = (ctx->lag_bvalid[prev] && ctx->lag_bn[prev] == n) ? prev : cur;
+        HIPCHK(hipEventSynchronize(ctx->lag_bev[use]));
+        bbox_finish(slot + 512 * use, bb);
+        ctx->lag_bvalid[cur] = true;
+        ctx->lag_bn[cur] = n;
+        ctx->lag_bslot = cur;
+    } else {
+        SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, true));
+    }
     if (ctx->clip_valid && bb[12] < 0.5 * (double)n)       // the clip box lost the cloud: re-anchor
         SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, false));
     double tmin[3], tmax[3];

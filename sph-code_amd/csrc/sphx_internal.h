@@ -142,6 +142,18 @@ struct sphx_ctx {
     int64_t step_count = 0;
     double dt_last = 0.0;
     hipEvent_t ev[10] = {nullptr};
+    // The fused step loop never waits for the step it is launching: its timing events live in a
+    // ring (collected two steps late), and the two host read-backs that size the grid - bounding
+    // box statistics and mean h - are taken from the PREVIOUS step's copies (slots in `pinned` at
+    // LAG_OFF; the grid box only steers performance: out-of-box particles are clamped into the
+    // boundary cells, which the search handles exactly).
+    hipEvent_t evring[3][10] = {{nullptr}};
+    unsigned ev_pending = 0;            // bit s: ring slot s holds an uncollected step
+    hipEvent_t lag_bev[2] = {nullptr, nullptr}, lag_hev[2] = {nullptr, nullptr};
+    bool lag_on = false;                // set by the fused loop around its grid build
+    bool lag_bvalid[2] = {false, false}, lag_hvalid[2] = {false, false};
+    int64_t lag_bn[2] = {0, 0};
+    int lag_bslot = 0, lag_hslot = 0;
     void* pinned = nullptr;       // small pinned host scratch for scalar read-back
 };
 
@@ -177,6 +189,7 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 // lanes-per-particle split of the LDS kernels (sphx_blob.hip), so all variants agree bit for bit.
 #ifndef SPHX_SUM_PARTS
 #define SPHX_SUM_PARTS 4
+#define LAG_OFF 1024                 // byte offset of the lag slots in ctx->pinned: slot s at LAG_OFF + 512 s (box), + 256 (h sums)
 #endif
 
 // scalar slots in ctx->scal (8-byte units)
