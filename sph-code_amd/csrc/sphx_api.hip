@@ -71,6 +71,15 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
     if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
+    if (const char* e = getenv("SPHX_KNN_ABL")) ctx->exp_knn = atoi(e);
+    if (const char* e = getenv("SPHX_BLOB_EXP")) ctx->exp_blob = atoi(e);
+    if (const char* e = getenv("SPHX_BLOB_EXP_LDS")) ctx->exp_blob_lds = (size_t)atoi(e);
+    if (const char* e = getenv("SPHX_PASS_EXP")) ctx->exp_pass = atoi(e);
+    if (const char* e = getenv("SPHX_BLOB_WGS")) {      // workgroups per CU of the LDS passes' persistent grid
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        if (atoi(e) > 0) ctx->blob_grid = ((cus * atoi(e) + 7) / 8) * 8;
+    }
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
@@ -116,7 +125,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
-                     &ctx->nontriv, &ctx->h_api};
+                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);

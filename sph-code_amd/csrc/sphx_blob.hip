@@ -502,9 +502,7 @@ int sphx_blob_grid(sphx_ctx* ctx, int nblk) {
     if (ctx->blob_grid <= 0) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        int per = 2;
-        if (const char* e = getenv("SPHX_BLOB_WGS")) per = atoi(e) > 0 ? atoi(e) : 2;
-        ctx->blob_grid = ((cus * per + 7) / 8) * 8;
+        ctx->blob_grid = ((cus * 2 + 7) / 8) * 8;
     }
     return nblk < ctx->blob_grid ? nblk : ctx->blob_grid;
 }
@@ -531,13 +529,13 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
-    if (const char* e = getenv("SPHX_BLOB_EXP")) {        // timing experiments, outputs discarded
+    if (ctx->exp_blob) {        // timing experiments (SPHX_BLOB_EXP), outputs discarded
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
         double* d = ctx->in_j.as<double>();
         size_t lds = IMG_BYTES(64, k);
-        if (const char* l = getenv("SPHX_BLOB_EXP_LDS")) lds = (size_t)atoi(l);      // e.g. 100000: one workgroup per CU
+        if (ctx->exp_blob_lds) lds = ctx->exp_blob_lds;      // e.g. 100000: one workgroup per CU
         for (int mode = 0; mode < 4; ++mode) {
-            if (!(atoi(e) & (1 << mode))) continue;
+            if (!(ctx->exp_blob & (1 << mode))) continue;
             hipEvent_t e0, e1;
             HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
             HIPCHK(hipEventRecord(e0, ctx->stream));

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = cell_of[i];
-    int slot = cell_start[c] + atomicAdd(&fill[c], 1);
+    int slot = cell_start[c] + atomicSub(&fill[c], 1) - 1;     // counts the histogram back down to zero
     perm[slot] = i;
 }
 
@@ -327,20 +327,27 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     SPHX_TRY(sphx_ensure(ctx, ctx->cell_of, (size_t)n * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->perm, (size_t)n * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->cell_start, ((size_t)nc + 2) * sizeof(int)));
+    const size_t fill_cap0 = ctx->cell_fill.cap;
     SPHX_TRY(sphx_ensure(ctx, ctx->cell_fill, ((size_t)nc + 2) * sizeof(int)));
+    if (ctx->cell_fill.cap != fill_cap0) ctx->cell_fill_zeroed = nullptr;       // a new allocation
     int nblk = (nc + SCAN_TILE - 1) / SCAN_TILE;
     SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, ((size_t)nblk + 2) * sizeof(int)));
     int* fill = ctx->cell_fill.as<int>();
     int* start = ctx->cell_start.as<int>();
     int* bsum = ctx->scan_tmp.as<int>();
-    HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));
+    // The histogram array is all zero between builds: cell_count counts it up, cell_scatter counts it
+    // back down while handing out slots (a cell's members are sorted afterwards anyway) - no memsets,
+    // except once for a new allocation.
+    if (ctx->cell_fill_zeroed != ctx->cell_fill.p) {
+        HIPCHK(hipMemsetAsync(fill, 0, ctx->cell_fill.cap, ctx->stream));
+        ctx->cell_fill_zeroed = ctx->cell_fill.p;
+    }
     int pb = (int)((n + 255) / 256);
     hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
                        ctx->cell_of.as<int>(), fill);
     hipLaunchKernelGGL(scan_phase1, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum);
     hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, nblk, bsum, bsum + nblk);
     hipLaunchKernelGGL(scan_phase3, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum, start);
-    HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>());
     hipLaunchKernelGGL(cell_sort_members, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, nc, start,

@@ -99,9 +99,12 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
 // ---- clipped sum of h (next grid's cell size) -------------------------------------------------
 // Escaped particles have kNN radii many orders of magnitude above the cloud's; values above
 // `clip` (8 x the previous mean) are left out.  out[0] += sum, out[3] += count (SC_HSUM, SC_HCNT).
-__global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, double clip, double* out_sum,
-                                                   double* out_cnt) {
+// No pre-zeroed accumulators: every block leaves its partial sums, the last one to finish (a ticket
+// that wraps back to 0 by itself) adds them up in block order - one launch, and the same bits every run.
+__global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, double clip, double* partial,
+                                                   unsigned* ticket, double* out_sum, double* out_cnt) {
     __shared__ double sm[4], sc[4];
+    __shared__ bool last;
     double s = 0.0, c = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double v = h[i];
@@ -112,31 +115,57 @@ __global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, doubl
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = s; sc[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(out_sum, sm[0] + sm[1] + sm[2] + sm[3]);
-        atomicAdd(out_cnt, sc[0] + sc[1] + sc[2] + sc[3]);
+        partial[2 * blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+        partial[2 * blockIdx.x + 1] = sc[0] + sc[1] + sc[2] + sc[3];
+        __threadfence();
+        last = atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {                                    // (wave-uniform: the whole block or none of it)
+        __threadfence();
+        double ts = 0.0, tc = 0.0;
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {      // fixed assignment and tree
+            ts += __builtin_nontemporal_load(&partial[2 * b]);
+            tc += __builtin_nontemporal_load(&partial[2 * b + 1]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ts += __shfl_xor(ts, o, 64); tc += __shfl_xor(tc, o, 64); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = ts; sc[threadIdx.x >> 6] = tc; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *out_sum = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+            *out_cnt = (sc[0] + sc[1]) + (sc[2] + sc[3]);
+        }
     }
 }
+#define HSUM_BLOCKS 512
 int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h) {
     double* out = ctx->scal.as<double>() + SC_HSUM;
     double* cnt = ctx->scal.as<double>() + SC_HCNT;
-    HIPCHK(hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
-    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(double), ctx->stream));
+    const bool fresh = ctx->hsum_tmp.p == nullptr;
+    SPHX_TRY(sphx_ensure(ctx, ctx->hsum_tmp, (size_t)(2 * HSUM_BLOCKS + 2) * sizeof(double)));
+    double* partial = ctx->hsum_tmp.as<double>();
+    unsigned* ticket = reinterpret_cast<unsigned*>(partial + 2 * HSUM_BLOCKS);
+    if (fresh) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(double), ctx->stream));
     int blocks = (int)((n + 255) / 256);
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, ctx->h_clip, out, cnt);
+    if (blocks > HSUM_BLOCKS) blocks = HSUM_BLOCKS;
+    hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, ctx->h_clip, partial, ticket,
+                       out, cnt);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
 
 // ---- drv:222-229: dt from the crossing time ------------------------------------------------
-__global__ void dt_kernel(const u64* ct_bits, double* dt_out, int first, double fixed_dt, double dt_0,
+__global__ void dt_kernel(u64* ct_bits, double* dt_out, int first, double fixed_dt, double dt_0,
                           double max_age) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double dt;
+    const u64 b = *ct_bits;
+    *ct_bits = 0x7F7F7F7F7F7F7F7Full;          // "none yet" again: the next step's pass 2 needs no memset
     if (fixed_dt > 0.0) {
         dt = fixed_dt;
     } else {
-        u64 b = *ct_bits;
         double ct = (b == 0x7F7F7F7F7F7F7F7Full) ? dt_0 / 10.0                       // nsc:783-784
                                                  : __longlong_as_double((long long)b) + 0.0001;  // nsc:786
         dt = first ? dt_0 / 10.0 : fmax(dt_0 / 5.0, fmin(dt_0 * 2.0, ct));           // drv:223-226
@@ -149,6 +178,7 @@ int sphx_compute_dt(sphx_ctx* ctx, int first, double fixed_dt) {
     hipLaunchKernelGGL(dt_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->scal.as<u64>() + SC_CT_BITS,
                        ctx->scal.as<double>() + SC_DT, first, fixed_dt, ctx->cst.dt_0, ctx->cst.max_age);
     HIPCHK(hipGetLastError());
+    ctx->ct_primed = true;
     return SPHX_OK;
 }
 

@@ -147,6 +147,13 @@ struct sphx_ctx {
     // box statistics and mean h - are taken from the PREVIOUS step's copies (slots in `pinned` at
     // LAG_OFF; the grid box only steers performance: out-of-box particles are clamped into the
     // boundary cells, which the search handles exactly).
+    // timing experiments (SPHX_KNN_ABL / SPHX_BLOB_EXP / SPHX_BLOB_EXP_LDS / SPHX_PASS_EXP: an extra,
+    // discarded launch of a cut-down kernel), read from the environment once, at sphx_create
+    const void* cell_fill_zeroed = nullptr;   // the cell_fill allocation known to be all zero between grid builds
+    bool ct_primed = false;             // SC_CT_BITS holds "none yet" (left so by dt_kernel)
+    DevBuf hsum_tmp;                    // hsum_kernel's per-block partial sums + its ticket
+    int exp_knn = -1, exp_blob = 0, exp_pass = -1;
+    size_t exp_blob_lds = 0;
     hipEvent_t evring[3][10] = {{nullptr}};
     unsigned ev_pending = 0;            // bit s: ring slot s holds an uncollected step
     hipEvent_t lag_bev[2] = {nullptr, nullptr}, lag_hev[2] = {nullptr, nullptr};

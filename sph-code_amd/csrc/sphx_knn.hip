@@ -15,7 +15,6 @@
 // Distances are accumulated as ((dx*dx + dy*dy) + dz*dz) without FMA contraction, the same
 // arithmetic SciPy's cKDTree uses, so orderings agree with the oracle bit for bit.
 #include "sphx_internal.h"
-#include <stdlib.h>
 
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
@@ -445,11 +444,11 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.h_by_id = out.h_by_id;
     a.counters = ctx->scal.as<u64>();
     int blocks = (int)(sphx_pad64(n) / KNN_PPB);
-    if (const char* e = getenv("SPHX_KNN_ABL")) {       // timing experiment, results discarded
+    if (ctx->exp_knn >= 0) {       // timing experiment (SPHX_KNN_ABL), results discarded
         KnnArgs b = a;
         b.nbr = nullptr; b.list64 = nullptr; b.dref = nullptr; b.h_sorted = nullptr; b.idx64 = nullptr; b.dist = nullptr; b.nontriv = nullptr;
         b.h_by_id = nullptr; b.counters = nullptr;
-        const int mode = atoi(e);
+        const int mode = ctx->exp_knn;
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, ctx->stream));

@@ -201,8 +201,8 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
     if (ctx->qorder && ctx->blob_lists) return sphx_blob_density(ctx, n, k);
-    if (const char* e = getenv("SPHX_PASS_EXP")) {        // timing experiment, outputs discarded
-        const int mode = atoi(e);
+    if (ctx->exp_pass >= 0) {        // timing experiment (SPHX_PASS_EXP), outputs discarded
+        const int mode = ctx->exp_pass;
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
         double* d = ctx->in_j.as<double>();
         hipEvent_t e0, e1;
@@ -316,7 +316,9 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
     SPHX_TRY(sphx_ensure(ctx, ctx->Pi, (size_t)n * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
-    HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));   // 0x7F7F.. = huge finite "none yet"
+    // 0x7F7F.. = huge finite "none yet"; in the fused loop the previous step's dt_kernel left it so
+    if (!ctx->ct_primed) HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));
+    ctx->ct_primed = false;
     if (ctx->qorder && ctx->blob_lists) return sphx_blob_pi(ctx, n, k, ct);
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(),
