@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = cell_of[i];
-    int slot = cell_start[c] + atomicSub(&fill[c], 1) - 1;     // counts the histogram back down to zero
+    // counts the histogram back down to zero; slots are handed out upwards (arrival order is mostly
+    // the previous cell order already, which the per-cell insertion sort then finds nearly sorted)
+    int slot = cell_start[c + 1] - atomicSub(&fill[c], 1);
     perm[slot] = i;
 }
 
