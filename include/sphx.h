@@ -107,7 +107,11 @@ int sphx_neighbors(sphx_ctx* ctx, int64_t n, int k, const double* points, double
  * visc_mode 0 = "ref_axis0": Pi_i = sum_k pi_ik, the axis repair of nsc:649.
  * Outputs keep the reference's sign (+grad P / rho) and layouts:
  *   hydro_accel, visc_accel (n,3); visc_heat, rho, nden, rho_dust (n,); f_un_nb (s,n).
- * Any output pointer may be NULL (that output is skipped).                              */
+ * Any output pointer may be NULL (that output is skipped).
+ * neighbor (here and in the loop forms below) may be NULL = "the (n,k) list of the previous array call
+ * on this context": the reference's loop passes one list to eight functions (drv:451-458), which is
+ * 320 MB of PCIe traffic each at N = 1e6, K = 40.  SPHX_E_STATE if no list of that shape is held
+ * (a search or a step on the context discards it).                                      */
 int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const int64_t* neighbor,
                       const double* points, const double* mass, const double* sizes,
                       const double* f_un, const double* particle_type, const double* T,

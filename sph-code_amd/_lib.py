@@ -28,6 +28,7 @@ class SphxStats(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/sphx.h declares
+SPHX_E_STATE = -4                # include/sphx.h
 _P = C.c_void_p
 _D = c_double_p
 _I = c_int64_p

@@ -81,6 +81,27 @@ def _nk(neighbor):
     return nb, nb.shape[0], nb.shape[1]
 
 
+# The driver hands ONE neighbour array to eight calls per step (drv:451-458).  neighbors() returns it
+# read-only; while that very object comes back, its device copy from the previous call is reused
+# (neighbor = NULL in the C call) instead of 8 N K bytes crossing PCIe again.
+_nb_held = None
+
+
+def _with_nb(neighbor, nb, call):
+    """call(pointer-or-None) -> rc, with the list of the previous call reused when it is this array."""
+    global _nb_held
+    c = context()
+    reusable = isinstance(neighbor, np.ndarray) and neighbor is nb and not neighbor.flags.writeable
+    if reusable and _nb_held is neighbor:
+        rc = call(None)
+        if rc != _lib.SPHX_E_STATE:              # (E_STATE: the context dropped the list: upload it)
+            c.check(rc)
+            return
+    _nb_held = None
+    c.check(call(ip(nb)))
+    _nb_held = neighbor if reusable else None
+
+
 def grain_mass(mineral_densities=mineral_densities, mrn_constants=mrn_constants):
     """nsc:76-79 (host-side constant table)."""
     return mineral_densities * -np.diff(mrn_constants ** 0.5) / np.diff(mrn_constants ** -2.5) \
@@ -106,7 +127,10 @@ def neighbors(points, dist, N_NEIGH, eps=0.1):
     h = np.empty(n, np.float64)
     c = context()
     bound = float(dist) if np.isfinite(dist) else 0.0
+    global _nb_held
+    _nb_held = None                                   # the search overwrites the context's list
     c.check(c.lib.sphx_neighbors(c.h, n, K, dp(pts), bound, float(eps), ip(idx), dp(dd), ip(nontriv), dp(h)))
+    idx.setflags(write=False)                         # (np.copy(neighbor), drv:172, is writeable again)
     return idx, None, dd, nontriv, h
 
 
@@ -128,9 +152,9 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
     c = context()
     c.check(c.lib.sphx_set_clip_grad(c.h, 1 if clip_grad else 0))
     try:
-        c.check(c.lib.sphx_hydro_update(c.h, n, K, S, ip(nb), dp(pts), dp(m), dp(h), dp(fu), dp(pt), dp(Tt),
-                                        dp(mu), dp(gam), dp(vel), 0, dp(ha), dp(va), dp(vh), dp(rho),
-                                        dp(nden), dp(F), dp(rhod)))
+        _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_hydro_update(
+            c.h, n, K, S, nbp, dp(pts), dp(m), dp(h), dp(fu), dp(pt), dp(Tt), dp(mu), dp(gam), dp(vel), 0,
+            dp(ha), dp(va), dp(vh), dp(rho), dp(nden), dp(F), dp(rhod)))
     finally:
         c.lib.sphx_set_clip_grad(c.h, 0)
     return ha, va, vh, rho, nden, F, rhod
@@ -141,8 +165,8 @@ def density(points, mass, particle_type, neighbor, d=None):
     nb, n, K = _nk(neighbor)
     out = np.empty(n)
     c = context()
-    c.check(c.lib.sphx_density(c.h, n, K, dp(f64(points, (n, 3))), dp(f64(mass, (n,))),
-                               dp(f64(particle_type, (n,))), ip(nb), _d(d), dp(out)))
+    pts, m, pt, dd = f64(points, (n, 3)), f64(mass, (n,)), f64(particle_type, (n,)), _d(d)
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_density(c.h, n, K, dp(pts), dp(m), dp(pt), nbp, dd, dp(out)))
     return out
 
 
@@ -151,8 +175,8 @@ def dust_density(points, mass, neighbor, particle_type, sizes):
     nb, n, K = _nk(neighbor)
     out = np.empty(n)
     c = context()
-    c.check(c.lib.sphx_dust_density(c.h, n, K, dp(f64(points, (n, 3))), dp(f64(mass, (n,))), ip(nb),
-                                    dp(f64(particle_type, (n,))), dp(f64(sizes, (n,))), dp(out)))
+    pts, m, pt, h = f64(points, (n, 3)), f64(mass, (n,)), f64(particle_type, (n,)), f64(sizes, (n,))
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_dust_density(c.h, n, K, dp(pts), dp(m), nbp, dp(pt), dp(h), dp(out)))
     return out
 
 
@@ -161,8 +185,8 @@ def num_dens(mass, points, mu_array, neighbor, d=None):
     nb, n, K = _nk(neighbor)
     out = np.empty(n)
     c = context()
-    c.check(c.lib.sphx_num_dens(c.h, n, K, dp(f64(mass, (n,))), dp(f64(points, (n, 3))),
-                                dp(f64(mu_array, (n,))), ip(nb), _d(d), dp(out)))
+    m, pts, mu, dd = f64(mass, (n,)), f64(points, (n, 3)), f64(mu_array, (n,)), _d(d)
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_num_dens(c.h, n, K, dp(m), dp(pts), dp(mu), nbp, dd, dp(out)))
     return out
 
 
@@ -171,9 +195,10 @@ def del_pressure(points, mass, particle_type, neighbor, E_internal, gamma_array,
     nb, n, K = _nk(neighbor)
     out = np.empty((n, 3))
     c = context()
-    c.check(c.lib.sphx_del_pressure(c.h, n, K, dp(f64(points, (n, 3))), dp(f64(mass, (n,))),
-                                    dp(f64(particle_type, (n,))), ip(nb), dp(f64(E_internal, (n,))),
-                                    dp(f64(gamma_array, (n,))), _d(d), dp(out)))
+    pts, m, pt = f64(points, (n, 3)), f64(mass, (n,)), f64(particle_type, (n,))
+    E, gam, dd = f64(E_internal, (n,)), f64(gamma_array, (n,)), _d(d)
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_del_pressure(c.h, n, K, dp(pts), dp(m), dp(pt), nbp, dp(E),
+                                                               dp(gam), dd, dp(out)))
     return out
 
 
@@ -183,10 +208,12 @@ def artificial_viscosity(neighbor, points, particle_type, sizes, mass, densities
     nb, n, K = _nk(neighbor)
     acc = np.empty((n, 3)); heat = np.empty(n)
     c = context()
-    c.check(c.lib.sphx_artificial_viscosity(
-        c.h, n, K, ip(nb), dp(f64(points, (n, 3))), dp(f64(particle_type, (n,))), dp(f64(sizes, (n,))),
-        dp(f64(mass, (n,))), dp(f64(densities, (n,))), dp(f64(velocities, (n, 3))), dp(f64(T, (n,))),
-        dp(f64(gamma_array, (n,))), dp(f64(mu_array, (n,))), _d(d), dp(acc), dp(heat)))
+    pts, pt, h, m = f64(points, (n, 3)), f64(particle_type, (n,)), f64(sizes, (n,)), f64(mass, (n,))
+    rho, vel, Tt = f64(densities, (n,)), f64(velocities, (n, 3)), f64(T, (n,))
+    gam, mu, dd = f64(gamma_array, (n,)), f64(mu_array, (n,)), _d(d)
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_artificial_viscosity(
+        c.h, n, K, nbp, dp(pts), dp(pt), dp(h), dp(m), dp(rho), dp(vel), dp(Tt), dp(gam), dp(mu), dd,
+        dp(acc), dp(heat)))
     return acc, heat
 
 
@@ -196,8 +223,8 @@ def crossing_time(neighbor, velocities, sizes, particle_type):
     out = np.empty(1)
     c = context()
     c.set_constants(dt_0=float(dt_0))
-    c.check(c.lib.sphx_crossing_time(c.h, n, K, ip(nb), dp(f64(velocities, (n, 3))), dp(f64(sizes, (n,))),
-                                     dp(f64(particle_type, (n,))), dp(out)))
+    vel, h, pt = f64(velocities, (n, 3)), f64(sizes, (n,)), f64(particle_type, (n,))
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_crossing_time(c.h, n, K, nbp, dp(vel), dp(h), dp(pt), dp(out)))
     return float(out[0])
 
 
@@ -211,9 +238,10 @@ def net_impulse(points, mass, sizes, velocities, particle_type, neighbor, f_un):
     mcs = np.ascontiguousarray(np.sum(seff * fu, axis=1))        # nsc:726
     onto = np.empty((n, 3)); react = np.empty((n, 3))
     c = context()
-    c.check(c.lib.sphx_net_impulse(c.h, n, K, dp(f64(points, (n, 3))), dp(f64(mass, (n,))),
-                                   dp(f64(sizes, (n,))), dp(f64(velocities, (n, 3))),
-                                   dp(f64(particle_type, (n,))), ip(nb), dp(mgm), dp(mcs), dp(onto), dp(react)))
+    pts, m, h = f64(points, (n, 3)), f64(mass, (n,)), f64(sizes, (n,))
+    vel, pt = f64(velocities, (n, 3)), f64(particle_type, (n,))
+    _with_nb(neighbor, nb, lambda nbp: c.lib.sphx_net_impulse(c.h, n, K, dp(pts), dp(m), dp(h), dp(vel), dp(pt),
+                                                              nbp, dp(mgm), dp(mcs), dp(onto), dp(react)))
     return onto, react
 
 

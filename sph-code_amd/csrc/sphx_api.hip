@@ -251,7 +251,7 @@ extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const i
                                  double* visc_accel, double* visc_heat, double* rho, double* nden,
                                  double* f_un_nb, double* rho_dust) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(neighbor); NEED(points); NEED(mass); NEED(sizes); NEED(particle_type); NEED(T);
+    NEED(points); NEED(mass); NEED(sizes); NEED(particle_type); NEED(T);
     NEED(mu_array); NEED(gamma_array); NEED(velocities);
     if (n < 1 || n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
     if (k < 1 || k > 4096) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d out of range", k);
@@ -262,7 +262,10 @@ extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const i
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
-    SPHX_TRY(upload(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
+    if (!neighbor && !(ctx->nbr_api_valid && ctx->nbr_api_n == n && ctx->nbr_api_k == k))
+        return sphx_set_err(ctx, SPHX_E_STATE, "neighbor == NULL but no (%lld, %d) list is held from a previous call",
+                            (long long)n, k);
+    if (neighbor) SPHX_TRY(upload(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
     SPHX_TRY(upload(ctx, ctx->in_a, points, 3 * nb));
     SPHX_TRY(upload(ctx, ctx->in_b, velocities, 3 * nb));
     SPHX_TRY(upload(ctx, ctx->in_c, mass, nb));
@@ -271,7 +274,10 @@ extern "C" int sphx_hydro_update(sphx_ctx* ctx, int64_t n, int k, int s, const i
     SPHX_TRY(upload(ctx, ctx->in_f, mu_array, nb));
     SPHX_TRY(upload(ctx, ctx->in_g, gamma_array, nb));
     SPHX_TRY(upload(ctx, ctx->in_h, particle_type, nb));
-    SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
+    if (neighbor) {
+        SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
+        ctx->nbr_api_valid = true; ctx->nbr_api_n = n; ctx->nbr_api_k = k;
+    }
     SPHX_TRY(sphx_prep(ctx, n, nullptr, nullptr, nullptr, ctx->in_a.as<double>(), nullptr, nullptr,
                        nullptr, ctx->in_b.as<double>(), ctx->in_c.as<double>(), ctx->in_d.as<double>(),
                        ctx->in_e.as<double>(), ctx->in_f.as<double>(), ctx->in_g.as<double>(),

@@ -150,6 +150,11 @@ struct sphx_ctx {
     // timing experiments (SPHX_KNN_ABL / SPHX_BLOB_EXP / SPHX_BLOB_EXP_LDS / SPHX_PASS_EXP: an extra,
     // discarded launch of a cut-down kernel), read from the environment once, at sphx_create
     const void* cell_fill_zeroed = nullptr;   // the cell_fill allocation known to be all zero between grid builds
+    // the K-major list in `nbr` is the caller-order list of the last array-API call with this shape
+    // (a later call may pass neighbor == NULL instead of uploading the same (N, K) int64 array again)
+    bool nbr_api_valid = false;
+    int64_t nbr_api_n = 0;
+    int nbr_api_k = 0;
     bool ct_primed = false;             // SC_CT_BITS holds "none yet" (left so by dt_kernel)
     DevBuf hsum_tmp;                    // hsum_kernel's per-block partial sums + its ticket
     int exp_knn = -1, exp_blob = 0, exp_pass = -1;

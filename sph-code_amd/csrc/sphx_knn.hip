@@ -419,6 +419,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
              double rscale, double rbound, const KnnOut& out) {
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "k=%d not in 1..%d", k, SPHX_MAX_K);
     if (n < 1 || n > (1ll << 29)) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range (1..2^29)", (long long)n);
+    ctx->nbr_api_valid = false;          // the K-major list is about to be overwritten
     KnnArgs a;
     a.n = (int)n;
     a.k = k;

@@ -209,8 +209,15 @@ static int loop_begin(sphx_ctx* ctx, int64_t n, int k, const int64_t* neighbor, 
     HIPCHK(hipSetDevice(ctx->device));
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
-    SPHX_TRY(up(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
-    SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
+    if (neighbor) {
+        SPHX_TRY(up(ctx, ctx->idx64, neighbor, (size_t)n * k * sizeof(int64_t)));
+        SPHX_TRY(sphx_transpose_nbr(ctx, n, k, ctx->idx64.as<int64_t>()));
+        ctx->nbr_api_valid = true; ctx->nbr_api_n = n; ctx->nbr_api_k = k;
+    } else if (!(ctx->nbr_api_valid && ctx->nbr_api_n == n && ctx->nbr_api_k == k)) {
+        // NULL = "the list of the previous call" (320 MB of PCIe traffic per call at N = 1e6, K = 40)
+        return sphx_set_err(ctx, SPHX_E_STATE, "neighbor == NULL but no (%lld, %d) list is held from a previous call",
+                            (long long)n, k);
+    }
     memset(a, 0, sizeof(*a));
     a->n = (int)n; a->npad = (int)sphx_pad64(n); a->k = k;
     a->nbr = ctx->nbr.as<int>();
@@ -236,7 +243,7 @@ static int down(sphx_ctx* ctx, void* host, const void* dev, size_t bytes) {
 extern "C" int sphx_density(sphx_ctx* ctx, int64_t n, int k, const double* points, const double* mass,
                             const double* particle_type, const int64_t* neighbor, double d, double* out) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(points); NEED(mass); NEED(particle_type); NEED(neighbor); NEED(out);
+    NEED(points); NEED(mass); NEED(particle_type); NEED(out);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_a, points, 3 * n, pos); UPF(in_c, mass, n, m); UPF(in_h, particle_type, n, pt);
@@ -251,7 +258,7 @@ extern "C" int sphx_dust_density(sphx_ctx* ctx, int64_t n, int k, const double* 
                                  const int64_t* neighbor, const double* particle_type,
                                  const double* sizes, double* out) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(points); NEED(mass); NEED(particle_type); NEED(neighbor); NEED(sizes); NEED(out);
+    NEED(points); NEED(mass); NEED(particle_type); NEED(sizes); NEED(out);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_a, points, 3 * n, pos); UPF(in_c, mass, n, m); UPF(in_h, particle_type, n, pt);
@@ -266,7 +273,7 @@ extern "C" int sphx_dust_density(sphx_ctx* ctx, int64_t n, int k, const double* 
 extern "C" int sphx_num_dens(sphx_ctx* ctx, int64_t n, int k, const double* mass, const double* points,
                              const double* mu_array, const int64_t* neighbor, double d, double* out) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(points); NEED(mass); NEED(mu_array); NEED(neighbor); NEED(out);
+    NEED(points); NEED(mass); NEED(mu_array); NEED(out);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_a, points, 3 * n, pos); UPF(in_c, mass, n, m); UPF(in_f, mu_array, n, mu);
@@ -281,7 +288,7 @@ extern "C" int sphx_del_pressure(sphx_ctx* ctx, int64_t n, int k, const double* 
                                  const double* particle_type, const int64_t* neighbor,
                                  const double* E_internal, const double* gamma_array, double d, double* out) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(points); NEED(mass); NEED(particle_type); NEED(neighbor); NEED(E_internal); NEED(gamma_array); NEED(out);
+    NEED(points); NEED(mass); NEED(particle_type); NEED(E_internal); NEED(gamma_array); NEED(out);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_a, points, 3 * n, pos); UPF(in_c, mass, n, m); UPF(in_h, particle_type, n, pt);
@@ -301,7 +308,7 @@ extern "C" int sphx_artificial_viscosity(sphx_ctx* ctx, int64_t n, int k, const 
                                          double* visc_accel, double* visc_heat) {
     if (!ctx) return SPHX_E_ARG;
     (void)sizes;
-    NEED(points); NEED(mass); NEED(particle_type); NEED(neighbor); NEED(densities); NEED(velocities);
+    NEED(points); NEED(mass); NEED(particle_type); NEED(densities); NEED(velocities);
     NEED(T); NEED(gamma_array); NEED(mu_array); NEED(visc_accel); NEED(visc_heat);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
@@ -321,7 +328,7 @@ extern "C" int sphx_crossing_time(sphx_ctx* ctx, int64_t n, int k, const int64_t
                                   const double* velocities, const double* sizes,
                                   const double* particle_type, double* out) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(neighbor); NEED(velocities); NEED(sizes); NEED(particle_type); NEED(out);
+    NEED(velocities); NEED(sizes); NEED(particle_type); NEED(out);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_b, velocities, 3 * n, vel); UPF(in_d, sizes, n, h); UPF(in_h, particle_type, n, pt);
@@ -346,7 +353,7 @@ extern "C" int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* p
                                 const int64_t* neighbor, const double* mean_grain_mass,
                                 const double* mean_cross, double* accel_onto, double* accel_reaction) {
     if (!ctx) return SPHX_E_ARG;
-    NEED(points); NEED(mass); NEED(sizes); NEED(velocities); NEED(particle_type); NEED(neighbor);
+    NEED(points); NEED(mass); NEED(sizes); NEED(velocities); NEED(particle_type);
     NEED(mean_grain_mass); NEED(mean_cross); NEED(accel_onto); NEED(accel_reaction);
     LoopArgs a;
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));

@@ -556,3 +556,49 @@ def test_degenerate_states_do_not_hang_the_step():
             assert out["points"].shape == (n, 3) and out["sizes"].shape == (n,), (name, kw)
             if name == "n_less_than_k" and not kw:
                 assert np.isfinite(out["points"]).all()
+
+
+def test_neighbour_list_is_uploaded_once_per_search(nsc, golden):
+    """The driver hands the array neighbors() returned to eight calls per step (drv:451-458): it comes
+    back read-only, and while that very object is passed its device copy is reused (neighbor = NULL in
+    the C call).  Same bits as with a fresh upload each time; a writeable copy is never reused; the C
+    entry point refuses NULL when it holds no list of that shape."""
+    import ctypes as C
+    g = golden
+    nsc.d = float(g["loop_d"])
+    P, m, pt = g["points"], g["mass"], g["particle_type"]
+    idx, _, _, _, h = nsc.neighbors(P, 1e300, int(g["nb_idx"].shape[1]))
+    assert not idx.flags.writeable and np.copy(idx).flags.writeable      # drv:172 copies it
+    fresh = lambda: np.copy(idx)                                          # writeable: uploaded every time
+    a0 = nsc.density(P, m, pt, idx)
+    assert nsc._nb_held is idx
+    a1 = nsc.dust_density(P, m, idx, pt, h)
+    a2 = nsc.del_pressure(P, m, pt, idx, g["E_internal"], g["gamma_array"])
+    a3 = nsc.artificial_viscosity(idx, P, pt, h, m, a0, g["velocities"], g["T"], g["gamma_array"], g["mu_array"])
+    a4 = nsc.crossing_time(idx, g["velocities"], h, pt)
+    hu = nsc.hydro_update(idx, P, m, h, g["f_un"], pt, g["T"], g["mu_array"], g["gamma_array"], g["velocities"])
+    assert nsc._nb_held is idx
+    b0 = nsc.density(P, m, pt, fresh())
+    assert nsc._nb_held is None
+    assert np.array_equal(a0, b0)
+    assert np.array_equal(a1, nsc.dust_density(P, m, fresh(), pt, h))
+    assert np.array_equal(a2, nsc.del_pressure(P, m, pt, fresh(), g["E_internal"], g["gamma_array"]))
+    b3 = nsc.artificial_viscosity(fresh(), P, pt, h, m, a0, g["velocities"], g["T"], g["gamma_array"], g["mu_array"])
+    assert np.array_equal(a3[0], b3[0]) and np.array_equal(a3[1], b3[1])
+    assert a4 == nsc.crossing_time(fresh(), g["velocities"], h, pt)
+    hv = nsc.hydro_update(fresh(), P, m, h, g["f_un"], pt, g["T"], g["mu_array"], g["gamma_array"], g["velocities"])
+    for x, y in zip(hu, hv):
+        assert np.array_equal(x, y)
+    # a search on the context drops the held list: the next call uploads again (and still agrees)
+    nsc.density(P, m, pt, idx)
+    assert nsc._nb_held is idx
+    idx2 = nsc.neighbors(P, 1e300, idx.shape[1])[0]
+    assert nsc._nb_held is None
+    c = nsc.context()
+    n, K = idx.shape
+    out = np.empty(n)
+    dp = lambda a_: a_.ctypes.data_as(C.POINTER(C.c_double))
+    rc = c.lib.sphx_density(c.h, n, K, dp(np.ascontiguousarray(P)), dp(np.ascontiguousarray(m)),
+                            dp(np.ascontiguousarray(pt)), None, nsc.d, dp(out))
+    assert rc == -4                                                       # SPHX_E_STATE
+    assert np.array_equal(nsc.density(P, m, pt, idx2), a0)
