@@ -216,12 +216,37 @@ __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, 
     // ---- far field: interaction lists, level by level ------------------------------------------------
     for (int l = 1; l < py.nlev; ++l) {
         const int X = fx >> l, Y = fy >> l, Z = fz >> l;
-        const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
         const int nxl = py.nx[l], nyl = py.ny[l], nzl = py.nz[l];
+        const double4* lev = pyr + py.off[l];
+        // From a few levels up the 64 particles of a wave (neighbours in blob order) sit in ONE cell and
+        // share its interaction list: the walk is then wave-uniform - scalar loop bounds, one scalar load
+        // per cell record instead of 64 lanes fetching the same 32 bytes, no divergence.  Same terms in
+        // the same order as the per-lane walk below.
+        const int Xu = __builtin_amdgcn_readfirstlane(X), Yu = __builtin_amdgcn_readfirstlane(Y),
+                  Zu = __builtin_amdgcn_readfirstlane(Z);
+        if (__builtin_amdgcn_ballot_w64(X != Xu || Y != Yu || Z != Zu) == 0ull) {
+            const int PXu = Xu >> 1, PYu = Yu >> 1, PZu = Zu >> 1;
+            const int ux0 = max(2 * (PXu - ws), 0), ux1 = min(2 * (PXu + ws) + 1, nxl - 1);
+            const int uy0 = max(2 * (PYu - ws), 0), uy1 = min(2 * (PYu + ws) + 1, nyl - 1);
+            const int uz0 = max(2 * (PZu - ws), 0), uz1 = min(2 * (PZu + ws) + 1, nzl - 1);
+            for (int kz = uz0; kz <= uz1; ++kz) {
+                const bool nz_ = abs(kz - Zu) <= ws;
+                for (int ky = uy0; ky <= uy1; ++ky) {
+                    const bool nyz = nz_ && abs(ky - Yu) <= ws;
+                    const double4* rowp = lev + ((size_t)kz * nyl + ky) * nxl;
+                    for (int kx = ux0; kx <= ux1; ++kx) {
+                        if (nyz && abs(kx - Xu) <= ws) continue;
+                        const double4 q = rowp[kx];
+                        if (q.x > 0.0) grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
+                    }
+                }
+            }
+            continue;
+        }
+        const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
         const int x0 = max(2 * (PX - ws), 0), x1 = min(2 * (PX + ws) + 1, nxl - 1);
         const int y0 = max(2 * (PY - ws), 0), y1 = min(2 * (PY + ws) + 1, nyl - 1);
         const int z0 = max(2 * (PZ - ws), 0), z1 = min(2 * (PZ + ws) + 1, nzl - 1);
-        const double4* lev = pyr + py.off[l];
         for (int kz = z0; kz <= z1; ++kz) {
             const bool nz_ = abs(kz - Z) <= ws;
             for (int ky = y0; ky <= y1; ++ky) {
