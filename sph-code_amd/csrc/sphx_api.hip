@@ -68,6 +68,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
+    if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
     if (const char* e = getenv("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
     if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);

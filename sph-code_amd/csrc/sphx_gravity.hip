@@ -174,13 +174,69 @@ __global__ __launch_bounds__(256) void pyr_up_kernel(Pyr py, int l, double4* pyr
     pyr[py.off[l] + c] = make_double4(sm, sx * inv, sy * inv, sz * inv);
 }
 
+// the same term where the softening guarantees r2 > 0 (no guard, no select)
+__device__ __forceinline__ void grav_term_soft(double qx, double qy, double qz, double qm, double xi, double yi,
+                                               double zi, double e2, double& ax, double& ay, double& az) {
+    const double dx = qx - xi, dy = qy - yi, dz = qz - zi;
+    const double r2 = dx * dx + dy * dy + dz * dz + e2;
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    const double inv = y0 * __builtin_fma(-0.5 * r2 * y0, y0, 1.5);
+    const double w = qm * (inv * inv * inv);
+    ax += w * dx; ay += w * dy; az += w * dz;
+}
 __device__ __forceinline__ void grav_term(double qx, double qy, double qz, double qm, double xi, double yi, double zi,
                                           double e2, double& ax, double& ay, double& az) {
     const double dx = qx - xi, dy = qy - yi, dz = qz - zi;
     const double r2 = dx * dx + dy * dy + dz * dz + e2;
-    const double inv = r2 > 0.0 ? rsqrt(r2) : 0.0;
+    // 1/sqrt: the hardware seed (v_rsq_f64, ~2^-26) and one Newton step (~2^-51) instead of the library
+    // routine's two steps, scaling and class checks - r2 sits mid-range (m^2), and a monopole sum that is
+    // good to 1e-3 has no use for the last bit.  (The exact direct sum above keeps rsqrt().)
+    double inv = 0.0;
+    if (r2 > 0.0) {
+        const double y0 = __builtin_amdgcn_rsq(r2);
+        inv = y0 * __builtin_fma(-0.5 * r2 * y0, y0, 1.5);
+    }
     const double w = qm * (inv * inv * inv);
     ax += w * dx; ay += w * dy; az += w * dz;
+}
+
+// per-lane walks (each thread its own loops and loads): the per-thread kernel, and the wave kernel's
+// fall-back where a wave's particles are not neighbours (blob order has a few long jumps)
+__device__ __forceinline__ void near_walk_lane(const GridParams& g, int ws, int fx, int fy, int fz,
+                                               const int* __restrict__ cell_start, const double* __restrict__ x,
+                                               const double* __restrict__ y, const double* __restrict__ z,
+                                               const double* __restrict__ m, double xi, double yi, double zi, double e2,
+                                               double& ax, double& ay, double& az) {
+    const int X = fx >> 1, Y = fy >> 1, Z = fz >> 1;
+    const int x0 = max(2 * (X - ws), 0), x1 = min(2 * (X + ws) + 2, g.nx);
+    const int y0 = max(2 * (Y - ws), 0), y1 = min(2 * (Y + ws) + 2, g.ny);
+    const int z0 = max(2 * (Z - ws), 0), z1 = min(2 * (Z + ws) + 2, g.nz);
+    for (int kz = z0; kz < z1; ++kz)
+        for (int ky = y0; ky < y1; ++ky) {
+            const int row = (kz * g.ny + ky) * g.nx;
+            const int s = cell_start[row + x0], e = cell_start[row + x1];
+            for (int j = s; j < e; ++j) grav_term(x[j], y[j], z[j], m[j], xi, yi, zi, e2, ax, ay, az);
+        }
+}
+__device__ __forceinline__ void far_walk_lane(int ws, int X, int Y, int Z, int nxl, int nyl, int nzl,
+                                              const double4* __restrict__ lev, double xi, double yi, double zi,
+                                              double e2, double& ax, double& ay, double& az) {
+    const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
+    const int x0 = max(2 * (PX - ws), 0), x1 = min(2 * (PX + ws) + 1, nxl - 1);
+    const int y0 = max(2 * (PY - ws), 0), y1 = min(2 * (PY + ws) + 1, nyl - 1);
+    const int z0 = max(2 * (PZ - ws), 0), z1 = min(2 * (PZ + ws) + 1, nzl - 1);
+    for (int kz = z0; kz <= z1; ++kz) {
+        const bool nz_ = abs(kz - Z) <= ws;
+        for (int ky = y0; ky <= y1; ++ky) {
+            const bool nyz = nz_ && abs(ky - Y) <= ws;
+            const double4* rowp = lev + ((size_t)kz * nyl + ky) * nxl;
+            for (int kx = x0; kx <= x1; ++kx) {
+                if (nyz && abs(kx - X) <= ws) continue;          // a neighbour: resolved at a finer level
+                const double4 q = rowp[kx];
+                if (q.x > 0.0) grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, Pyr py, int ws,
@@ -200,68 +256,174 @@ __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, 
     const int c0 = cell_of_sorted[i];
     const int fx = c0 % g.nx, fy = (c0 / g.nx) % g.ny, fz = c0 / (g.nx * g.ny);
     double ax = 0.0, ay = 0.0, az = 0.0;
-    // ---- near field: particles of the level-1 cells within +-ws of the particle's level-1 cell ----
+    near_walk_lane(g, ws, fx, fy, fz, cell_start, x, y, z, m, xi, yi, zi, e2, ax, ay, az);
+    for (int l = 1; l < py.nlev; ++l)
+        far_walk_lane(ws, fx >> l, fy >> l, fz >> l, py.nx[l], py.ny[l], py.nz[l], pyr + py.off[l], xi, yi, zi, e2,
+                      ax, ay, az);
+    const int o = omap ? omap[i] : i;
+    acc[3 * (size_t)o] = G * ax; acc[3 * (size_t)o + 1] = G * ay; acc[3 * (size_t)o + 2] = G * az;
+}
+
+// ---- the same sum, one WAVE per 64 particles working through LDS -----------------------------------
+// The 64 particles of a wave are neighbours (blob order), so their near regions and interaction lists
+// overlap almost entirely.  At every level the wave takes the UNION box of its lanes' lists, stages it
+// plane by plane into LDS with coalesced loads (each cell record / particle once per wave, not once per
+// lane), and every lane runs over the staged records with broadcast LDS reads, a per-lane bit mask
+// saying which of them belong to ITS list.  A lane adds its own terms in the same order as the
+// per-thread kernel above (masked ones add +0): the result is bit-identical to it.
+#define GT_CB 192                       // cell records / particles staged per wave
+#define GT_SLACK 4                      // cells a wave's union box may exceed one lane's box by, per axis
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+// bits a..b (inclusive) of a 32-bit word, the range clipped to 0..31
+__device__ __forceinline__ unsigned range_bits(int a, int b) {
+    a = max(a, 0); b = min(b, 31);
+    if (b < a) return 0u;
+    const unsigned upto_b = (b == 31) ? 0xFFFFFFFFu : ((2u << b) - 1u);
+    return upto_b & ~((1u << a) - 1u);
+}
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void gravity_tree_wave_kernel(int n, GridParams g, Pyr py, int ws,
+                                                                const int* __restrict__ cell_of_sorted,
+                                                                const int* __restrict__ cell_start,
+                                                                const double* __restrict__ x, const double* __restrict__ y,
+                                                                const double* __restrict__ z, const double* __restrict__ m,
+                                                                const double4* __restrict__ pyr, const double* eps_ptr,
+                                                                double eps_val, double G, const int* __restrict__ qorder,
+                                                                const int* __restrict__ omap, double* acc) {
+    __shared__ double4 cbuf_all[4][GT_CB];
+    __shared__ int ibuf_all[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double4* cbuf = cbuf_all[wave];
+    int* ibuf = ibuf_all[wave];
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const bool act = p < n;
+    if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;          // (a wave past the end)
+    const int i = act ? (qorder ? qorder[p] : p) : 0;
+    const double eps = eps_ptr ? *eps_ptr : eps_val;
+    const double e2 = eps * eps;
+    const bool soft = e2 > 1e-290;                                  // (wave-uniform)
+    const double xi = x[i], yi = y[i], zi = z[i];
+    int c0 = cell_of_sorted[i];
+    c0 = act ? c0 : __builtin_amdgcn_readfirstlane(c0);             // idle lanes (last wave) shadow lane 0
+    const int fx = c0 % g.nx, fy = (c0 / g.nx) % g.ny, fz = c0 / (g.nx * g.ny);
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    // ---- near field: particles of the level-1 cells within +-ws of the lane's level-1 cell ---------
     {
         const int X = fx >> 1, Y = fy >> 1, Z = fz >> 1;
-        const int x0 = max(2 * (X - ws), 0), x1 = min(2 * (X + ws) + 2, g.nx);
-        const int y0 = max(2 * (Y - ws), 0), y1 = min(2 * (Y + ws) + 2, g.ny);
-        const int z0 = max(2 * (Z - ws), 0), z1 = min(2 * (Z + ws) + 2, g.nz);
-        for (int kz = z0; kz < z1; ++kz)
-            for (int ky = y0; ky < y1; ++ky) {
+        const int lx0 = max(2 * (X - ws), 0), lx1 = min(2 * (X + ws) + 2, g.nx) - 1;      // fine cells, inclusive
+        const int ly0 = max(2 * (Y - ws), 0), ly1 = min(2 * (Y + ws) + 2, g.ny) - 1;
+        const int lz0 = max(2 * (Z - ws), 0), lz1 = min(2 * (Z + ws) + 2, g.nz) - 1;
+        const int ux0 = wave_min_i(lx0), ux1 = wave_max_i(lx1);
+        const int uy0 = wave_min_i(ly0), uy1 = wave_max_i(ly1);
+        const int uz0 = wave_min_i(lz0), uz1 = wave_max_i(lz1);
+        // the wave's particles are neighbours: its union box is little more than one lane's box
+        const int own = 4 * ws + 2 + GT_SLACK;
+        const bool compact = ux1 - ux0 < own && uy1 - uy0 < own && uz1 - uz0 < own;
+        if (!compact) near_walk_lane(g, ws, fx, fy, fz, cell_start, x, y, z, m, xi, yi, zi, e2, ax, ay, az);
+        for (int kz = uz0; compact && kz <= uz1; ++kz) {
+            const bool zin = kz >= lz0 && kz <= lz1;
+            for (int ky = uy0; ky <= uy1; ++ky) {
+                const bool rowin = zin && ky >= ly0 && ky <= ly1;
                 const int row = (kz * g.ny + ky) * g.nx;
-                const int s = cell_start[row + x0], e = cell_start[row + x1];
-                for (int j = s; j < e; ++j) grav_term(x[j], y[j], z[j], m[j], xi, yi, zi, e2, ax, ay, az);
+                const int s = __builtin_amdgcn_readfirstlane(cell_start[row + ux0]);
+                const int e = __builtin_amdgcn_readfirstlane(cell_start[row + ux1 + 1]);
+                for (int j0 = s; j0 < e; j0 += 64) {
+                    const int cnt = min(64, e - j0);
+                    if (lane < cnt) {
+                        const int j = j0 + lane;
+                        cbuf[lane] = make_double4(x[j], y[j], z[j], m[j]);
+                        ibuf[lane] = cell_of_sorted[j] - row;                   // the particle's fine x cell
+                    }
+                    lds_sync();
+                    for (int t = 0; t < cnt; ++t) {
+                        const double4 q = cbuf[t];
+                        const int cx = ibuf[t];
+                        const bool mine = rowin && cx >= lx0 && cx <= lx1;
+                        grav_term(q.x, q.y, q.z, mine ? q.w : 0.0, xi, yi, zi, e2, ax, ay, az);
+                    }
+                    lds_sync();
+                }
             }
+        }
     }
     // ---- far field: interaction lists, level by level ------------------------------------------------
     for (int l = 1; l < py.nlev; ++l) {
         const int X = fx >> l, Y = fy >> l, Z = fz >> l;
+        const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
         const int nxl = py.nx[l], nyl = py.ny[l], nzl = py.nz[l];
+        const int lx0 = max(2 * (PX - ws), 0), lx1 = min(2 * (PX + ws) + 1, nxl - 1);
+        const int ly0 = max(2 * (PY - ws), 0), ly1 = min(2 * (PY + ws) + 1, nyl - 1);
+        const int lz0 = max(2 * (PZ - ws), 0), lz1 = min(2 * (PZ + ws) + 1, nzl - 1);
         const double4* lev = pyr + py.off[l];
-        // From a few levels up the 64 particles of a wave (neighbours in blob order) sit in ONE cell and
-        // share its interaction list: the walk is then wave-uniform - scalar loop bounds, one scalar load
-        // per cell record instead of 64 lanes fetching the same 32 bytes, no divergence.  Same terms in
-        // the same order as the per-lane walk below.
-        const int Xu = __builtin_amdgcn_readfirstlane(X), Yu = __builtin_amdgcn_readfirstlane(Y),
-                  Zu = __builtin_amdgcn_readfirstlane(Z);
-        if (__builtin_amdgcn_ballot_w64(X != Xu || Y != Yu || Z != Zu) == 0ull) {
-            const int PXu = Xu >> 1, PYu = Yu >> 1, PZu = Zu >> 1;
-            const int ux0 = max(2 * (PXu - ws), 0), ux1 = min(2 * (PXu + ws) + 1, nxl - 1);
-            const int uy0 = max(2 * (PYu - ws), 0), uy1 = min(2 * (PYu + ws) + 1, nyl - 1);
-            const int uz0 = max(2 * (PZu - ws), 0), uz1 = min(2 * (PZu + ws) + 1, nzl - 1);
-            for (int kz = uz0; kz <= uz1; ++kz) {
-                const bool nz_ = abs(kz - Zu) <= ws;
-                for (int ky = uy0; ky <= uy1; ++ky) {
-                    const bool nyz = nz_ && abs(ky - Yu) <= ws;
-                    const double4* rowp = lev + ((size_t)kz * nyl + ky) * nxl;
-                    for (int kx = ux0; kx <= ux1; ++kx) {
-                        if (nyz && abs(kx - Xu) <= ws) continue;
-                        const double4 q = rowp[kx];
-                        if (q.x > 0.0) grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
-                    }
-                }
-            }
+        const int ux0 = wave_min_i(lx0), ux1 = wave_max_i(lx1);
+        const int uy0 = wave_min_i(ly0), uy1 = wave_max_i(ly1);
+        const int uz0 = wave_min_i(lz0), uz1 = wave_max_i(lz1);
+        const int W = ux1 - ux0 + 1;
+        const int own = 4 * ws + 2 + GT_SLACK;
+        if (W > 32 || W > own || uy1 - uy0 >= own || uz1 - uz0 >= own) {
+            // a wave spread over more cells than neighbours would be: the per-lane walk
+            far_walk_lane(ws, X, Y, Z, nxl, nyl, nzl, lev, xi, yi, zi, e2, ax, ay, az);
             continue;
         }
-        const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
-        const int x0 = max(2 * (PX - ws), 0), x1 = min(2 * (PX + ws) + 1, nxl - 1);
-        const int y0 = max(2 * (PY - ws), 0), y1 = min(2 * (PY + ws) + 1, nyl - 1);
-        const int z0 = max(2 * (PZ - ws), 0), z1 = min(2 * (PZ + ws) + 1, nzl - 1);
-        for (int kz = z0; kz <= z1; ++kz) {
-            const bool nz_ = abs(kz - Z) <= ws;
-            for (int ky = y0; ky <= y1; ++ky) {
-                const bool nyz = nz_ && abs(ky - Y) <= ws;
-                const double4* rowp = lev + ((size_t)kz * nyl + ky) * nxl;
-                for (int kx = x0; kx <= x1; ++kx) {
-                    if (nyz && abs(kx - X) <= ws) continue;          // a neighbour: resolved at a finer level
-                    const double4 q = rowp[kx];
-                    if (q.x > 0.0) grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
+        const unsigned xlist = range_bits(lx0 - ux0, lx1 - ux0);          // the lane's x range within the union row
+        const unsigned xnear = range_bits(X - ws - ux0, X + ws - ux0);    // ... and its own neighbourhood in it
+        const int rpc = GT_CB / W;                                        // rows staged at a time
+        for (int kz = uz0; kz <= uz1; ++kz) {
+            const bool zin = kz >= lz0 && kz <= lz1;
+            const bool znear = abs(kz - Z) <= ws;
+            for (int kyc = uy0; kyc <= uy1; kyc += rpc) {
+                const int nr = min(rpc, uy1 - kyc + 1);
+                for (int r = 0; r < nr; ++r)
+                    if (lane < W) cbuf[r * W + lane] = lev[((size_t)kz * nyl + (kyc + r)) * nxl + ux0 + lane];
+                lds_sync();
+                for (int r = 0; r < nr; ++r) {
+                    const int ky = kyc + r;
+                    const bool yin = zin && ky >= ly0 && ky <= ly1;
+                    const bool near_row = znear && abs(ky - Y) <= ws;
+                    const unsigned bits = yin ? (near_row ? (xlist & ~xnear) : xlist) : 0u;
+                    const double4* rowq = cbuf + r * W;
+                    if (soft) {
+                        // r2 >= eps^2 > 0: no guard; two records in flight per trip
+                        int t = 0;
+                        for (; t + 1 < W; t += 2) {
+                            const double4 q0 = rowq[t], q1 = rowq[t + 1];
+                            grav_term_soft(q0.y, q0.z, q0.w, ((bits >> t) & 1u) ? q0.x : 0.0, xi, yi, zi, e2, ax, ay, az);
+                            grav_term_soft(q1.y, q1.z, q1.w, ((bits >> (t + 1)) & 1u) ? q1.x : 0.0, xi, yi, zi, e2, ax, ay, az);
+                        }
+                        if (t < W) {
+                            const double4 q0 = rowq[t];
+                            grav_term_soft(q0.y, q0.z, q0.w, ((bits >> t) & 1u) ? q0.x : 0.0, xi, yi, zi, e2, ax, ay, az);
+                        }
+                    } else {
+                        for (int t = 0; t < W; ++t) {
+                            const double4 q = rowq[t];
+                            if (!(q.x > 0.0)) continue;                           // (uniform: an empty cell)
+                            grav_term(q.y, q.z, q.w, ((bits >> t) & 1u) ? q.x : 0.0, xi, yi, zi, e2, ax, ay, az);
+                        }
+                    }
                 }
+                lds_sync();
             }
         }
     }
-    const int o = omap ? omap[i] : i;
-    acc[3 * (size_t)o] = G * ax; acc[3 * (size_t)o + 1] = G * ay; acc[3 * (size_t)o + 2] = G * az;
+    if (act) {
+        const int o = omap ? omap[i] : i;
+        acc[3 * (size_t)o] = G * ax; acc[3 * (size_t)o + 1] = G * ay; acc[3 * (size_t)o + 2] = G * az;
+    }
 }
 
 __global__ __launch_bounds__(256) void gather1_kernel(int n, const int* perm, const double* in, double* out) {
@@ -304,9 +466,14 @@ int sphx_gravity_tree_launch(sphx_ctx* ctx, int64_t n, const double* x, const do
     }
     hipLaunchKernelGGL(sorted_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->grav_cell.as<int>());
-    hipLaunchKernelGGL(gravity_tree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, py,
-                       ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, eps_dev, eps, G,
-                       ctx->qorder, omap, acc);
+    if (ctx->grav_per_thread)         // SPHX_GRAV_KERNEL=0: the per-thread walk (the wave kernel's reference)
+        hipLaunchKernelGGL(gravity_tree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, py,
+                           ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, eps_dev, eps, G,
+                           ctx->qorder, omap, acc);
+    else
+        hipLaunchKernelGGL(gravity_tree_wave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           g, py, ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, eps_dev, eps,
+                           G, ctx->qorder, omap, acc);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

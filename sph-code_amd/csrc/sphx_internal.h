@@ -99,6 +99,7 @@ struct sphx_ctx {
     double grav_G = 0.0;
     DevBuf grav, grav_sort, grav_tmp;   // (n,3) accelerations, sorted h, radix-sort scratch
     DevBuf grav_pyr, grav_cell;         // cell pyramid (mass, centre of mass), fine cell of each sorted particle
+    bool grav_per_thread = false;       // SPHX_GRAV_KERNEL=0: tree walk per thread instead of per wave through LDS
     int grav_ws = 2;                    // well-separatedness of the tree form (cells)
     // ---- Verlet refresh (sphx_refresh.hip) ----
     DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current

@@ -134,3 +134,36 @@ def test_gpu_step_tree_gravity_tracks_direct():
     diff = np.sqrt(np.mean(np.sum((rb["total_accel"] - ra["total_accel"]) ** 2, axis=1)))
     assert diff < 1e-2 * gs
     assert b.stats()["ms_gravity"] > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n", [("polytrope", 30000), ("uniform_cube", 9000), ("polytrope", 70)])
+def test_gpu_tree_wave_kernel_is_the_per_thread_walk(workload, n, monkeypatch):
+    """The wave-cooperative LDS form of the tree walk adds every lane's terms in the order of the
+    per-thread walk (SPHX_GRAV_KERNEL=0) - the same sum up to how the compiler contracts the two loops'
+    multiply-adds (last bits) - at both separations, also when the last wave is partly idle and when
+    there are fewer particles than a wave."""
+    import ctypes as C
+    import sph_code_amd.ics as ics
+    from sph_code_amd import _lib
+    from scipy.spatial import cKDTree
+    st = ics.WORKLOADS[workload](n, light=True)
+    p = np.ascontiguousarray(st["points"]); m = np.ascontiguousarray(st["mass"])
+    k = min(40, n)
+    h = np.ascontiguousarray(cKDTree(p).query(p, k=k)[0][:, -1])
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+
+    def run(per_thread, ws):
+        if per_thread:
+            monkeypatch.setenv("SPHX_GRAV_KERNEL", "0")
+        else:
+            monkeypatch.delenv("SPHX_GRAV_KERNEL", raising=False)
+        c = _lib.Context()
+        out = np.empty((n, 3))
+        c.check(c.lib.sphx_gravity_tree(c.h, n, dp(m), dp(p), dp(h), 0.0, 6.67430e-11, ws, 40, dp(out)))
+        return out
+
+    for ws in (1, 2):
+        a, b = run(True, ws), run(False, ws)
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max(), (ws, np.abs(a - b).max() / np.abs(a).max())
