@@ -102,6 +102,26 @@ class Exchanger:
         self.rank, self.world, self.comm_device = rank, world, comm_device
         self.bytes_sent = 0
 
+    def warm_up(self):
+        """One element to and from every peer: whatever a backend sets up lazily per pair of ranks (RCCL:
+        a communicator per pair, tens to hundreds of ms) happens here and not when a particle first
+        migrates to a rank this one had no halo with."""
+        if self.world == 1:
+            return
+        ops, keep = [], []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            t = torch.full((1,), float(self.rank), dtype=torch.float64, device=self.comm_device)
+            r = torch.empty(1, dtype=torch.float64, device=self.comm_device)
+            ops += [dist.P2POp(dist.isend, t, p), dist.P2POp(dist.irecv, r, p)]
+            keep += [(p, r), (None, t)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for p, r in keep:
+            if p is not None and float(r[0]) != float(p):
+                raise RuntimeError("halo warm-up: rank %d got %r from rank %d" % (self.rank, float(r[0]), p))
+
     def counts(self, send_counts):
         """send_counts (world,) -> recv_counts (world,) (what each peer will send to me)."""
         if self.world == 1:
@@ -282,6 +302,7 @@ class DistributedSim:
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
         self.ex = Exchanger(rank, world, self.comm_device)
+        self.ex.warm_up()
         f = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
         self.s = dict(pos=f(state["points"]), vel=f(state["velocities"]), m=f(state["mass"]), T=f(state["T"]),
                       mu=f(state["mu_array"]), gam=f(state["gamma_array"]), ptype=f(state["particle_type"]),
