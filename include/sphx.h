@@ -162,11 +162,13 @@ int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* points, cons
 int sphx_gravity_direct(sphx_ctx* ctx, int64_t n, const double* mass, const double* points,
                         const double* sizes, double softening, double G, double* accel);
 
-/* The same sum by monopoles of a cell pyramid over a search-style grid (cells sized for k_cells
- * neighbours, 40 if < 1): level-l cells of 2^l fine cells a side carry (mass, centre of mass); a
- * particle sums the cells that are children of its parent's +-ws neighbours but not its own +-ws
- * neighbours, level by level, and the particles of the +-ws level-1 cells directly.  ws = 1..4
- * (1: ~1 % rms force error, 2: ~0.2 %).  Every monopole is softened like a particle (nsc:385).    */
+/* The same sum by multipoles of a cell pyramid over a search-style grid (cells sized for k_cells
+ * neighbours, 40 if < 1): level-l cells of 2^l fine cells a side carry (mass, centre of mass) and, at
+ * order 2 (sphx_set_gravity_order; the default), their second moments; a particle sums the cells that
+ * are children of its parent's +-ws neighbours but not its own +-ws neighbours, level by level, and
+ * the particles of the +-ws level-1 cells directly.  ws = 1..4.  rms force error against the exact sum:
+ * order 2: ~0.1 % at ws = 1, ~0.01 % at ws = 2; order 1: ~1 %, ~0.2 %.  Every cell is softened like a
+ * particle (nsc:385): the expansion is that of the softened kernel.                                 */
 int sphx_gravity_tree(sphx_ctx* ctx, int64_t n, const double* mass, const double* points,
                       const double* sizes, double softening, double G, int ws, int k_cells,
                       double* accel);
@@ -216,10 +218,15 @@ int sphx_set_clip_grad(sphx_ctx* ctx, int on);
 /* Self-gravity inside the step loop (drv:448-449,477): mode 1 = direct summation with Plummer
  * softening eps = median(h) of the step (nsc:358), G m_j (x_j - x_i) / (|x_j - x_i|^2 + eps^2)^(3/2)
  * summed over ALL particles - the sum the reference's tree approximates (sphx_gravity_direct).
- * O(N^2): meant for N up to a few 10^5.  mode 2 = the same sum by cell-pyramid monopoles
- * (sphx_gravity_tree, ws = 2; SPHX_GRAV_WS overrides), ~1e4 terms per particle.  mode 0 switches it
- * off.  Call after sphx_state_upload. */
+ * O(N^2): meant for N up to a few 10^5.  mode 2 = the same sum by cell-pyramid multipoles
+ * (sphx_gravity_tree with ws = 1, order 2; SPHX_GRAV_WS / sphx_set_gravity_order override), ~1.5e3 terms
+ * per particle.  mode 0 switches it off.  Call after sphx_state_upload. */
 int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G);
+/* Multipole order of the tree's cells (sphx_gravity_tree and mode 2 above): 1 = monopoles, 2 (default) =
+ * monopoles + second moments about each cell's centre of mass, the second-order Taylor term of the
+ * softened kernel - ws = 1 then beats the accuracy monopoles need ws = 2 for, at 40 % of the cost
+ * (DESIGN 5.7).                                                                                         */
+int sphx_set_gravity_order(sphx_ctx* ctx, int order);
 /* One or more passes of the hot path.  k = N_NEIGH, dist = distance_upper_bound of
  * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);
  * fixed_dt > 0 overrides the crossing-time rule (drv:225-229).                           */

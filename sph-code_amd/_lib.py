@@ -57,6 +57,7 @@ SIGNATURES = {
     "sphx_state_set_loop_forms": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_set_clip_grad": (C.c_int, [_P, C.c_int]),
     "sphx_state_set_gravity": (C.c_int, [_P, C.c_int, C.c_double]),
+    "sphx_set_gravity_order": (C.c_int, [_P, C.c_int]),
     "sphx_gravity_direct": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, _D]),
     "sphx_gravity_tree": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, C.c_int, C.c_int, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),

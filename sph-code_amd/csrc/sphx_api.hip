@@ -69,6 +69,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
     if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
+    if (const char* e = getenv("SPHX_GRAV_ORDER")) { int v = atoi(e); if (v == 1 || v == 2) ctx->grav_order = v; }
     if (const char* e = getenv("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
     if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
@@ -126,7 +127,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
-                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp};
+                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -385,6 +386,13 @@ extern "C" int sphx_state_set_loop_forms(sphx_ctx* ctx, int on, double d) {
     if (on && ctx->use_verlet) return sphx_set_err(ctx, SPHX_E_STATE, "loop-form steps are not combined with incremental search");
     ctx->loop_forms = on ? 1 : 0;
     ctx->loop_d = d;
+    return SPHX_OK;
+}
+
+extern "C" int sphx_set_gravity_order(sphx_ctx* ctx, int order) {
+    if (!ctx) return SPHX_E_ARG;
+    if (order != 1 && order != 2) return sphx_set_err(ctx, SPHX_E_ARG, "gravity order %d not 1 (monopole) or 2 (quadrupole)", order);
+    ctx->grav_order = order;
     return SPHX_OK;
 }
 

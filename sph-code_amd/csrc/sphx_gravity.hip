@@ -136,7 +136,7 @@ struct Pyr {
 __global__ __launch_bounds__(256) void pyr_level1_kernel(GridParams g, Pyr py, const int* __restrict__ cell_start,
                                                          const double* __restrict__ x, const double* __restrict__ y,
                                                          const double* __restrict__ z, const double* __restrict__ m,
-                                                         double4* pyr) {
+                                                         double4* pyr, double4* quad) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int nx1 = py.nx[1], ny1 = py.ny[1], nz1 = py.nz[1];
     if (c >= nx1 * ny1 * nz1) return;
@@ -153,10 +153,28 @@ __global__ __launch_bounds__(256) void pyr_level1_kernel(GridParams g, Pyr py, c
             }
         }
     const double inv = sm > 0.0 ? 1.0 / sm : 0.0;
-    pyr[py.off[1] + c] = make_double4(sm, sx * inv, sy * inv, sz * inv);
+    const double cxm = sx * inv, cym = sy * inv, czm = sz * inv;
+    pyr[py.off[1] + c] = make_double4(sm, cxm, cym, czm);
+    if (quad) {
+        // second moments about the centre of mass, S_ab = sum m d_a d_b (not made traceless: the
+        // softened kernel is not harmonic, its expansion keeps the trace)
+        double qxx = 0.0, qyy = 0.0, qzz = 0.0, qxy = 0.0, qxz = 0.0, qyz = 0.0;
+        for (int fz = 2 * Z; fz < min(2 * Z + 2, g.nz); ++fz)
+            for (int fy = 2 * Y; fy < min(2 * Y + 2, g.ny); ++fy) {
+                const int row = (fz * g.ny + fy) * g.nx;
+                const int s = cell_start[row + fx0], e = cell_start[row + fx1];
+                for (int j = s; j < e; ++j) {
+                    const double mj = m[j], dx = x[j] - cxm, dy = y[j] - cym, dz = z[j] - czm;
+                    qxx += mj * dx * dx; qyy += mj * dy * dy; qzz += mj * dz * dz;
+                    qxy += mj * dx * dy; qxz += mj * dx * dz; qyz += mj * dy * dz;
+                }
+            }
+        quad[2 * (py.off[1] + c)] = make_double4(qxx, qyy, qzz, qxy);
+        quad[2 * (py.off[1] + c) + 1] = make_double4(qxz, qyz, 0.0, 0.0);
+    }
 }
 
-__global__ __launch_bounds__(256) void pyr_up_kernel(Pyr py, int l, double4* pyr) {
+__global__ __launch_bounds__(256) void pyr_up_kernel(Pyr py, int l, double4* pyr, double4* quad) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int nxl = py.nx[l], nyl = py.ny[l], nzl = py.nz[l];
     if (c >= nxl * nyl * nzl) return;
@@ -171,7 +189,47 @@ __global__ __launch_bounds__(256) void pyr_up_kernel(Pyr py, int l, double4* pyr
                 sm += q.x; sx += q.x * q.y; sy += q.x * q.z; sz += q.x * q.w;
             }
     const double inv = sm > 0.0 ? 1.0 / sm : 0.0;
-    pyr[py.off[l] + c] = make_double4(sm, sx * inv, sy * inv, sz * inv);
+    const double cxm = sx * inv, cym = sy * inv, czm = sz * inv;
+    pyr[py.off[l] + c] = make_double4(sm, cxm, cym, czm);
+    if (quad) {
+        // S = sum over children of S_child + M_child s s^T, s = child's centre - this centre
+        const double4* qh = quad + 2 * py.off[l - 1];
+        double qxx = 0.0, qyy = 0.0, qzz = 0.0, qxy = 0.0, qxz = 0.0, qyz = 0.0;
+        for (int k = 2 * Z; k < min(2 * Z + 2, cz); ++k)
+            for (int j = 2 * Y; j < min(2 * Y + 2, cy); ++j)
+                for (int i = 2 * X; i < min(2 * X + 2, cx); ++i) {
+                    const size_t cc = ((size_t)k * cy + j) * cx + i;
+                    const double4 q = ch[cc];
+                    if (!(q.x > 0.0)) continue;
+                    const double4 b = qh[2 * cc], e = qh[2 * cc + 1];
+                    const double dx = q.y - cxm, dy = q.z - cym, dz = q.w - czm;
+                    qxx += b.x + q.x * dx * dx; qyy += b.y + q.x * dy * dy; qzz += b.z + q.x * dz * dz;
+                    qxy += b.w + q.x * dx * dy; qxz += e.x + q.x * dx * dz; qyz += e.y + q.x * dy * dz;
+                }
+        quad[2 * (py.off[l] + c)] = make_double4(qxx, qyy, qzz, qxy);
+        quad[2 * (py.off[l] + c) + 1] = make_double4(qxz, qyz, 0.0, 0.0);
+    }
+}
+
+// Monopole + second moments of a cell (M at c, S_ab = sum m d_a d_b about c) on a particle at x, r = c - x:
+// the Taylor expansion of the SOFTENED kernel 1 / sqrt(r^2 + eps^2) to second order, s^2 = r^2 + eps^2,
+//   a = (M / s^3 + 15/2 (r.S.r) / s^7 - 3/2 tr(S) / s^5) r - 3 (S.r) / s^5
+// (for eps = 0 this is the usual traceless-quadrupole term).  f = 1 for a cell of the lane's list, else 0.
+// Needs s2 > 0: softening, or a cell that is not the particle's own - a well-separated cell never is.
+__device__ __forceinline__ void grav_term_quad(double4 a4, double4 b4, double4 c4, double f, double xi, double yi,
+                                               double zi, double e2, double& ax, double& ay, double& az) {
+    const double dx = a4.y - xi, dy = a4.z - yi, dz = a4.w - zi;
+    const double r2 = dx * dx + dy * dy + dz * dz + e2;
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    const double inv = y0 * __builtin_fma(-0.5 * r2 * y0, y0, 1.5);
+    const double inv2 = inv * inv, inv3 = inv * inv2, inv5 = inv3 * inv2, inv7 = inv5 * inv2;
+    const double srx = b4.x * dx + b4.w * dy + c4.x * dz;
+    const double sry = b4.w * dx + b4.y * dy + c4.y * dz;
+    const double srz = c4.x * dx + c4.y * dy + b4.z * dz;
+    const double rsr = dx * srx + dy * sry + dz * srz;
+    const double tr = b4.x + b4.y + b4.z;
+    const double cr = f * (a4.x * inv3 + 7.5 * rsr * inv7 - 1.5 * tr * inv5), cq = f * 3.0 * inv5;
+    ax += cr * dx - cq * srx; ay += cr * dy - cq * sry; az += cr * dz - cq * srz;
 }
 
 // the same term where the softening guarantees r2 > 0 (no guard, no select)
@@ -219,7 +277,8 @@ __device__ __forceinline__ void near_walk_lane(const GridParams& g, int ws, int 
         }
 }
 __device__ __forceinline__ void far_walk_lane(int ws, int X, int Y, int Z, int nxl, int nyl, int nzl,
-                                              const double4* __restrict__ lev, double xi, double yi, double zi,
+                                              const double4* __restrict__ lev, const double4* __restrict__ qlev,
+                                              double xi, double yi, double zi,
                                               double e2, double& ax, double& ay, double& az) {
     const int PX = X >> 1, PY = Y >> 1, PZ = Z >> 1;
     const int x0 = max(2 * (PX - ws), 0), x1 = min(2 * (PX + ws) + 1, nxl - 1);
@@ -233,7 +292,13 @@ __device__ __forceinline__ void far_walk_lane(int ws, int X, int Y, int Z, int n
             for (int kx = x0; kx <= x1; ++kx) {
                 if (nyz && abs(kx - X) <= ws) continue;          // a neighbour: resolved at a finer level
                 const double4 q = rowp[kx];
-                if (q.x > 0.0) grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
+                if (!(q.x > 0.0)) continue;
+                if (qlev) {
+                    const size_t cc = ((size_t)kz * nyl + ky) * nxl + kx;
+                    grav_term_quad(q, qlev[2 * cc], qlev[2 * cc + 1], 1.0, xi, yi, zi, e2, ax, ay, az);
+                } else {
+                    grav_term(q.y, q.z, q.w, q.x, xi, yi, zi, e2, ax, ay, az);
+                }
             }
         }
     }
@@ -244,7 +309,8 @@ __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, 
                                                            const int* __restrict__ cell_start,
                                                            const double* __restrict__ x, const double* __restrict__ y,
                                                            const double* __restrict__ z, const double* __restrict__ m,
-                                                           const double4* __restrict__ pyr, const double* eps_ptr,
+                                                           const double4* __restrict__ pyr,
+                                                           const double4* __restrict__ quad, const double* eps_ptr,
                                                            double eps_val, double G, const int* __restrict__ qorder,
                                                            const int* __restrict__ omap, double* acc) {
     const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -258,8 +324,8 @@ __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, 
     double ax = 0.0, ay = 0.0, az = 0.0;
     near_walk_lane(g, ws, fx, fy, fz, cell_start, x, y, z, m, xi, yi, zi, e2, ax, ay, az);
     for (int l = 1; l < py.nlev; ++l)
-        far_walk_lane(ws, fx >> l, fy >> l, fz >> l, py.nx[l], py.ny[l], py.nz[l], pyr + py.off[l], xi, yi, zi, e2,
-                      ax, ay, az);
+        far_walk_lane(ws, fx >> l, fy >> l, fz >> l, py.nx[l], py.ny[l], py.nz[l], pyr + py.off[l],
+                      quad ? quad + 2 * py.off[l] : nullptr, xi, yi, zi, e2, ax, ay, az);
     const int o = omap ? omap[i] : i;
     acc[3 * (size_t)o] = G * ax; acc[3 * (size_t)o + 1] = G * ay; acc[3 * (size_t)o + 2] = G * az;
 }
@@ -296,15 +362,19 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// QUAD: cells carry quadrupoles too (three 32-B pieces per staged cell, half as many cells per stage)
+template <bool QUAD>
 __global__ __launch_bounds__(256) void gravity_tree_wave_kernel(int n, GridParams g, Pyr py, int ws,
                                                                 const int* __restrict__ cell_of_sorted,
                                                                 const int* __restrict__ cell_start,
                                                                 const double* __restrict__ x, const double* __restrict__ y,
                                                                 const double* __restrict__ z, const double* __restrict__ m,
-                                                                const double4* __restrict__ pyr, const double* eps_ptr,
+                                                                const double4* __restrict__ pyr,
+                                                                const double4* __restrict__ quad, const double* eps_ptr,
                                                                 double eps_val, double G, const int* __restrict__ qorder,
                                                                 const int* __restrict__ omap, double* acc) {
-    __shared__ double4 cbuf_all[4][GT_CB];
+    constexpr int CB = QUAD ? GT_CB / 2 : GT_CB;      // cells staged at a time
+    __shared__ double4 cbuf_all[4][QUAD ? 3 * (GT_CB / 2) : GT_CB];
     __shared__ int ibuf_all[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double4* cbuf = cbuf_all[wave];
@@ -376,19 +446,25 @@ __global__ __launch_bounds__(256) void gravity_tree_wave_kernel(int n, GridParam
         const int own = 4 * ws + 2 + GT_SLACK;
         if (W > 32 || W > own || uy1 - uy0 >= own || uz1 - uz0 >= own) {
             // a wave spread over more cells than neighbours would be: the per-lane walk
-            far_walk_lane(ws, X, Y, Z, nxl, nyl, nzl, lev, xi, yi, zi, e2, ax, ay, az);
+            far_walk_lane(ws, X, Y, Z, nxl, nyl, nzl, lev, QUAD ? quad + 2 * py.off[l] : nullptr, xi, yi, zi, e2,
+                          ax, ay, az);
             continue;
         }
+        const double4* qlev = QUAD ? quad + 2 * py.off[l] : nullptr;
         const unsigned xlist = range_bits(lx0 - ux0, lx1 - ux0);          // the lane's x range within the union row
         const unsigned xnear = range_bits(X - ws - ux0, X + ws - ux0);    // ... and its own neighbourhood in it
-        const int rpc = GT_CB / W;                                        // rows staged at a time
+        const int rpc = CB / W;                                           // rows staged at a time
         for (int kz = uz0; kz <= uz1; ++kz) {
             const bool zin = kz >= lz0 && kz <= lz1;
             const bool znear = abs(kz - Z) <= ws;
             for (int kyc = uy0; kyc <= uy1; kyc += rpc) {
                 const int nr = min(rpc, uy1 - kyc + 1);
                 for (int r = 0; r < nr; ++r)
-                    if (lane < W) cbuf[r * W + lane] = lev[((size_t)kz * nyl + (kyc + r)) * nxl + ux0 + lane];
+                    if (lane < W) {
+                        const size_t cc = ((size_t)kz * nyl + (kyc + r)) * nxl + ux0 + lane;
+                        cbuf[r * W + lane] = lev[cc];
+                        if (QUAD) { cbuf[CB + r * W + lane] = qlev[2 * cc]; cbuf[2 * CB + r * W + lane] = qlev[2 * cc + 1]; }
+                    }
                 lds_sync();
                 for (int r = 0; r < nr; ++r) {
                     const int ky = kyc + r;
@@ -396,7 +472,14 @@ __global__ __launch_bounds__(256) void gravity_tree_wave_kernel(int n, GridParam
                     const bool near_row = znear && abs(ky - Y) <= ws;
                     const unsigned bits = yin ? (near_row ? (xlist & ~xnear) : xlist) : 0u;
                     const double4* rowq = cbuf + r * W;
-                    if (soft) {
+                    if (QUAD) {
+                        for (int t = 0; t < W; ++t) {
+                            const double4 q = rowq[t];
+                            if (!(q.x > 0.0)) continue;                           // (uniform: an empty cell)
+                            grav_term_quad(q, rowq[CB + t], rowq[2 * CB + t], ((bits >> t) & 1u) ? 1.0 : 0.0, xi, yi, zi,
+                                           e2, ax, ay, az);
+                        }
+                    } else if (soft) {
                         // r2 >= eps^2 > 0: no guard; two records in flight per trip
                         int t = 0;
                         for (; t + 1 < W; t += 2) {
@@ -457,23 +540,32 @@ int sphx_gravity_tree_launch(sphx_ctx* ctx, int64_t n, const double* x, const do
     SPHX_TRY(sphx_ensure(ctx, ctx->grav_pyr, (size_t)tot * sizeof(double4)));
     SPHX_TRY(sphx_ensure(ctx, ctx->grav_cell, (size_t)n * sizeof(int)));
     double4* pyr = ctx->grav_pyr.as<double4>();
+    double4* quad = nullptr;                            // order 2: two more 32-B pieces per cell
+    if (ctx->grav_order >= 2) {
+        SPHX_TRY(sphx_ensure(ctx, ctx->grav_quad, (size_t)tot * 2 * sizeof(double4)));
+        quad = ctx->grav_quad.as<double4>();
+    }
     const int n1 = py.nx[1] * py.ny[1] * py.nz[1];
     hipLaunchKernelGGL(pyr_level1_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, ctx->stream, g, py,
-                       ctx->cell_start.as<int>(), x, y, z, m, pyr);
+                       ctx->cell_start.as<int>(), x, y, z, m, pyr, quad);
     for (int q = 2; q <= py.nlev; ++q) {
         const int nq = py.nx[q] * py.ny[q] * py.nz[q];
-        hipLaunchKernelGGL(pyr_up_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, py, q, pyr);
+        hipLaunchKernelGGL(pyr_up_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream, py, q, pyr, quad);
     }
     hipLaunchKernelGGL(sorted_cells_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->grav_cell.as<int>());
     if (ctx->grav_per_thread)         // SPHX_GRAV_KERNEL=0: the per-thread walk (the wave kernel's reference)
         hipLaunchKernelGGL(gravity_tree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, py,
-                           ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, eps_dev, eps, G,
+                           ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, quad, eps_dev, eps, G,
                            ctx->qorder, omap, acc);
+    else if (quad)
+        hipLaunchKernelGGL(gravity_tree_wave_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (int)n, g, py, ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, quad,
+                           eps_dev, eps, G, ctx->qorder, omap, acc);
     else
-        hipLaunchKernelGGL(gravity_tree_wave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                           g, py, ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, eps_dev, eps,
-                           G, ctx->qorder, omap, acc);
+        hipLaunchKernelGGL(gravity_tree_wave_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (int)n, g, py, ws, ctx->grav_cell.as<int>(), ctx->cell_start.as<int>(), x, y, z, m, pyr, quad,
+                           eps_dev, eps, G, ctx->qorder, omap, acc);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

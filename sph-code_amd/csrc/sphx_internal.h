@@ -99,8 +99,10 @@ struct sphx_ctx {
     double grav_G = 0.0;
     DevBuf grav, grav_sort, grav_tmp;   // (n,3) accelerations, sorted h, radix-sort scratch
     DevBuf grav_pyr, grav_cell;         // cell pyramid (mass, centre of mass), fine cell of each sorted particle
+    int grav_order = 2;                 // multipole order of the tree's cells: 1 monopoles, 2 + second moments (sphx_set_gravity_order)
+    DevBuf grav_quad;
     bool grav_per_thread = false;       // SPHX_GRAV_KERNEL=0: tree walk per thread instead of per wave through LDS
-    int grav_ws = 2;                    // well-separatedness of the tree form (cells)
+    int grav_ws = 1;                    // well-separatedness of the tree form (cells)
     // ---- Verlet refresh (sphx_refresh.hip) ----
     DevBuf list64, dref, pos0, pos4;   // int32[n][64], f64[n], f64[3n] positions at list build, f64[4n] packed current
     bool list_valid = false, use_verlet = false;   // opt-in (sphx_set_incremental): pays only for slow drift
