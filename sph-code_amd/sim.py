@@ -16,7 +16,7 @@ from ._lib import dp, f64
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
                  incremental=False, with_drag=False, gravity=None, G=6.67430e-11, clip_grad=False,
-                 forms="hydro_update", d=None):
+                 forms="hydro_update", d=None, gravity_order=2):
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -46,6 +46,8 @@ class Simulation:
             if gravity not in ("direct", "tree"):
                 raise ValueError("gravity must be None, 'direct' or 'tree'")
             c.check(c.lib.sphx_state_set_gravity(c.h, 1 if gravity == "direct" else 2, float(G)))
+            # tree: cells carry their second moments (order 2, ~0.1 % rms force error) or monopoles only (1, ~1 %)
+            c.check(c.lib.sphx_set_gravity_order(c.h, int(gravity_order)))
         if with_drag:
             # per-particle mean grain mass / cross-section as nsc.net_impulse forms them (nsc:720-726)
             from . import compat
