@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void gravity_tree_kernel(int n, GridParams g, 
 // saying which of them belong to ITS list.  A lane adds its own terms in the same order as the
 // per-thread kernel above (masked ones add +0): the result is bit-identical to it.
 #define GT_CB 192                       // cell records / particles staged per wave
-#define GT_SLACK 4                      // cells a wave's union box may exceed one lane's box by, per axis
+#ifndef GT_SLACK
+#define GT_SLACK 1                      // cells a wave's union box may exceed one lane's box by, per axis
+#endif
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
