@@ -231,6 +231,9 @@ int sphx_set_gravity_order(sphx_ctx* ctx, int order);
  * nsc:544 (<= 0 or inf: unbounded), first != 0: the first step uses dt_0/10 (drv:223-224);
  * fixed_dt > 0 overrides the crossing-time rule (drv:225-229).                           */
 int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int first, double fixed_dt);
+/* Any output pointer may be NULL.  The particle state (pos ... sizes) belongs to the loop alone; rho, nden
+ * and visc_heat are the last step's pass outputs, which live in work buffers the array entry points above
+ * also use - ask for them before calling those on the same context (or give the loop a context of its own). */
 int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, double* accel,
                         double* E_internal, double* T, double* sizes, double* rho,
                         double* nden, double* visc_heat, double* dt_last);

@@ -602,3 +602,43 @@ def test_neighbour_list_is_uploaded_once_per_search(nsc, golden):
                             dp(np.ascontiguousarray(pt)), None, nsc.d, dp(out))
     assert rc == -4                                                       # SPHX_E_STATE
     assert np.array_equal(nsc.density(P, m, pt, idx2), a0)
+
+
+def test_array_api_calls_between_steps_do_not_disturb_the_loop(nsc, golden):
+    """One context, the fused loop and the array API taking turns (a driver that reads diagnostics through
+    nsc.* between steps): searches, sums and a gravity call on OTHER particles in between leave the loop's
+    trajectory bit for bit what it is without them (grid box statistics, histogram, crossing-time slot and
+    neighbour-list bookkeeping are all per call)."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    from sph_code_amd import _lib
+    s0 = ics.polytrope_sphere(20000)
+    ref = Simulation(s0, n_neigh=40, ctx=_lib.Context())
+    ref.step(6)
+    want = ref.download()
+
+    ctx = _lib.Context()
+    sim = Simulation(s0, n_neigh=40, ctx=ctx)
+    g = golden
+    P, m, pt = g["points"], g["mass"], g["particle_type"]
+    old_ctx, nsc._ctx = nsc._ctx, ctx                    # the module's calls now share the loop's context
+    try:
+        nsc._ctx.set_constants(k_B=nsc.k, amu=nsc.amu, m_h=nsc.m_h, m_0=nsc.m_0, dt_0=nsc.dt_0)
+        nsc.d = float(g["loop_d"])
+        for it in range(3):
+            sim.step(2)
+            idx, _, _, _, h = nsc.neighbors(P, 1e300, int(g["nb_idx"].shape[1]))
+            rho = nsc.density(P, m, pt, idx)
+            nsc.crossing_time(idx, g["velocities"], h, pt)
+            nsc.hydro_update(idx, P, m, h, g["f_un"], pt, g["T"], g["mu_array"], g["gamma_array"], g["velocities"])
+            nsc.grav_force_tree(m, P, h)
+            assert np.isfinite(rho).all()
+    finally:
+        nsc._ctx = old_ctx
+        nsc._nb_held = None
+    got = sim.download()
+    # (the state; download's diagnostics - densities ... - are the last pass outputs in work buffers the
+    #  array calls share, include/sphx.h)
+    for key in ("points", "velocities", "total_accel", "E_internal", "T", "sizes"):
+        assert np.array_equal(got[key], want[key]), key
+    assert got["dt"] == want["dt"]
