@@ -23,6 +23,7 @@
 #ifndef SPHX_H
 #define SPHX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -78,6 +79,12 @@ int         sphx_create(sphx_ctx** out, int device);
 void        sphx_destroy(sphx_ctx* ctx);
 const char* sphx_last_error(const sphx_ctx* ctx);
 int         sphx_version(void);
+/* Page-locked host memory for the big arrays the array entry points hand back ((N,K) int64 + float64 from
+ * sphx_neighbors: 640 MB at N = 1e6, K = 40): device-to-host copies into it run at the link's rate instead of
+ * being staged through the runtime's bounce buffers (~4x).  Any host pointer is accepted everywhere; this is
+ * an optimisation a binding may use for its output arrays.  SPHX_E_NOMEM if the pages cannot be locked.   */
+int         sphx_host_alloc(void** out, size_t bytes);
+int         sphx_host_free(void* p);
 int         sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c);
 int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
 /* Search tuning (performance only, never results): the step loop searches inside

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -37,6 +38,8 @@ SIGNATURES = {
     "sphx_destroy": (None, [_P]),
     "sphx_last_error": (C.c_char_p, [_P]),
     "sphx_version": (C.c_int, []),
+    "sphx_host_alloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
+    "sphx_host_free": (C.c_int, [_P]),
     "sphx_set_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
     "sphx_get_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
     "sphx_set_tuning": (C.c_int, [_P, C.c_double, C.c_double]),
@@ -119,6 +122,51 @@ def i64(a, shape=None):
     if shape is not None and out.shape != shape:
         raise ValueError("expected shape %s, got %s" % (shape, out.shape))
     return out
+
+
+class _PinnedPool:
+    """Page-locked host buffers for large result arrays (include/sphx.h sphx_host_alloc).  A buffer backs a
+    NumPy array; when the last view of it dies the buffer returns to the pool (locking pages costs more than
+    the copy it speeds up, so buffers are reused, a few per size).  Falls back to ordinary memory when pages
+    cannot be locked."""
+    MIN_BYTES = 8 << 20
+    KEEP_PER_SIZE = 3
+
+    def __init__(self):
+        self.free = {}
+        self.lock = threading.Lock()
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        with self.lock:
+            lst = self.free.get(nbytes)
+            ptr = lst.pop() if lst else None
+        if ptr is None:
+            lib = load_library()
+            p = _P()
+            if lib.sphx_host_alloc(C.byref(p), nbytes) != 0 or not p.value:
+                return np.empty(shape, dtype)
+            ptr = p.value
+        buf = (C.c_byte * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, nbytes)       # (runs when the last array over buf is gone)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _release(self, ptr, nbytes):
+        with self.lock:
+            lst = self.free.setdefault(nbytes, [])
+            if len(lst) < self.KEEP_PER_SIZE:
+                lst.append(ptr)
+                return
+        try:
+            load_library().sphx_host_free(_P(ptr))
+        except Exception:
+            pass
+
+
+pinned = _PinnedPool()
 
 
 def dp(a):

@@ -121,11 +121,11 @@ def neighbors(points, dist, N_NEIGH, eps=0.1):
     if pts.ndim != 2 or pts.shape[1] != 3:
         raise ValueError("points must be (N, 3)")
     n, K = pts.shape[0], int(N_NEIGH)
-    idx = np.empty((n, K), np.int64)
-    dd = np.empty((n, K), np.float64)
+    c = context()
+    idx = _lib.pinned.empty((n, K), np.int64)         # 8 N K bytes each: page-locked when large (4x the copy rate)
+    dd = _lib.pinned.empty((n, K), np.float64)
     nontriv = np.empty(n, np.int64)
     h = np.empty(n, np.float64)
-    c = context()
     bound = float(dist) if np.isfinite(dist) else 0.0
     global _nb_held
     _nb_held = None                                   # the search overwrites the context's list

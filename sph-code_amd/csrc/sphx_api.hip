@@ -47,6 +47,22 @@ static void default_constants(sphx_constants* c) {
 
 extern "C" int sphx_version(void) { return 100; }
 
+extern "C" int sphx_host_alloc(void** out, size_t bytes) {
+    if (!out) return SPHX_E_ARG;
+    *out = nullptr;
+    if (bytes == 0) bytes = 8;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return SPHX_E_NOMEM;
+    }
+    return SPHX_OK;
+}
+extern "C" int sphx_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) return SPHX_E_HIP;
+    return SPHX_OK;
+}
+
 extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (!out) return SPHX_E_ARG;
     *out = nullptr;
