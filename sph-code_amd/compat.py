@@ -147,8 +147,9 @@ def hydro_update(neighbor, points, mass, sizes, f_un, particle_type, T, mu_array
     if fu.ndim != 2 or fu.shape[0] != n:
         raise ValueError("f_un must be (N, S)")
     S = fu.shape[1]
-    ha = np.empty((n, 3)); va = np.empty((n, 3)); vh = np.empty(n)
-    rho = np.empty(n); nden = np.empty(n); F = np.empty((S, n)); rhod = np.empty(n)
+    pe = _lib.pinned.empty                          # page-locked when large: faster device-to-host copies
+    ha = pe((n, 3), np.float64); va = pe((n, 3), np.float64); vh = np.empty(n)
+    rho = np.empty(n); nden = np.empty(n); F = pe((S, n), np.float64); rhod = np.empty(n)
     c = context()
     c.check(c.lib.sphx_set_clip_grad(c.h, 1 if clip_grad else 0))
     try:
@@ -193,7 +194,7 @@ def num_dens(mass, points, mu_array, neighbor, d=None):
 def del_pressure(points, mass, particle_type, neighbor, E_internal, gamma_array, d=None):
     """nsc:755-774."""
     nb, n, K = _nk(neighbor)
-    out = np.empty((n, 3))
+    out = _lib.pinned.empty((n, 3), np.float64)
     c = context()
     pts, m, pt = f64(points, (n, 3)), f64(mass, (n,)), f64(particle_type, (n,))
     E, gam, dd = f64(E_internal, (n,)), f64(gamma_array, (n,)), _d(d)
@@ -206,7 +207,7 @@ def artificial_viscosity(neighbor, points, particle_type, sizes, mass, densities
                          gamma_array, mu_array, d=None):
     """nsc:788-816 -> (visc_accel (N,3), visc_heat (N,))."""
     nb, n, K = _nk(neighbor)
-    acc = np.empty((n, 3)); heat = np.empty(n)
+    acc = _lib.pinned.empty((n, 3), np.float64); heat = np.empty(n)
     c = context()
     pts, pt, h, m = f64(points, (n, 3)), f64(particle_type, (n,)), f64(sizes, (n,)), f64(mass, (n,))
     rho, vel, Tt = f64(densities, (n,)), f64(velocities, (n, 3)), f64(T, (n,))
@@ -236,7 +237,7 @@ def net_impulse(points, mass, sizes, velocities, particle_type, neighbor, f_un):
     seff = sigma_effective(mineral_densities, mrn_constants, mu_specie)
     mgm = np.ascontiguousarray(np.sum(meff * fu, axis=1))        # nsc:725 (per particle)
     mcs = np.ascontiguousarray(np.sum(seff * fu, axis=1))        # nsc:726
-    onto = np.empty((n, 3)); react = np.empty((n, 3))
+    onto = _lib.pinned.empty((n, 3), np.float64); react = _lib.pinned.empty((n, 3), np.float64)
     c = context()
     pts, m, h = f64(points, (n, 3)), f64(mass, (n,)), f64(sizes, (n,))
     vel, pt = f64(velocities, (n, 3)), f64(particle_type, (n,))
