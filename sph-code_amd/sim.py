@@ -73,6 +73,8 @@ class Simulation:
             dp(out["T"]), dp(out["sizes"]), dp(out["densities"]), dp(out["num_densities"]),
             dp(out["visc_heat"]), C.cast(C.byref(dt), _lib.c_double_p)))
         out["dt"] = dt.value
+        # P_i = n_i k_B T_i: the reference forms it and drops it (commented out at nsc:608); derived here
+        out["pressure"] = out["num_densities"] * self.ctx.constants().k_B * out["T"]
         return out
 
     # ---- snapshot / restart and per-step diagnostics (the reference only wrote summary
