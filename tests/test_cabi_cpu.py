@@ -100,3 +100,15 @@ def test_oracle_step_runs():
     assert r["dt"] == orc.DT_0 / 10
     r2 = orc.step(r, n_neigh=40, eps=0.0, first=False)
     assert orc.DT_0 / 5 <= r2["dt"] <= 2 * orc.DT_0
+
+
+def test_pinned_pool_falls_back_to_ordinary_memory_without_a_gpu():
+    """compat hands large results back in page-locked buffers (sphx_host_alloc); where pages cannot be
+    locked - no HIP device here - the pool must quietly return ordinary arrays of the right shape."""
+    from sph_code_amd import _lib
+    a = _lib.pinned.empty((3 << 20,), np.float64)           # above the pool's size threshold
+    assert a.shape == (3 << 20,) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+    a[:4] = 1.0
+    b = _lib.pinned.empty((10, 3), np.float64)              # small: never pooled
+    assert b.shape == (10, 3)
+    del a
