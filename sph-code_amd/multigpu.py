@@ -420,13 +420,18 @@ class DistributedSim:
         cell = self._coarse_cell(self.s["pos"])
         mask = maps[:, cell] != 0                                             # (W, n)
         mask[self.rank] = False
+        # counts to every peer, exchanged while still on the device: one host read at the end serves both the
+        # send lists and what the peers will send (each read drains the stream)
+        cnt = mask.sum(dim=1).to(self.comm_device)                            # (W,) int64
+        allc = [torch.zeros_like(cnt) for _ in range(W)]
+        dist.all_gather(allc, cnt)
         pk = torch.nonzero(mask)                                              # sorted by peer, then particle
-        counts = torch.bincount(pk[:, 0], minlength=W).tolist() if pk.numel() else [0] * W
+        both = torch.stack([cnt, torch.stack(allc)[:, self.rank]]).tolist()
+        counts, recv_counts = both[0], both[1]
         send_idx, o = [], 0
         for p in range(W):
             send_idx.append(None if p == self.rank else pk[o:o + counts[p], 1].contiguous())
             o += counts[p]
-        recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
         return send_idx, recv_counts
 
     # rows <-> separate arrays.  Backends with fused kernels (LibBackend) do each in one launch; the
