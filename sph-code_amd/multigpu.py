@@ -675,12 +675,16 @@ class DistributedSim:
             own_l = owner[leave]
             o2 = torch.argsort(own_l, stable=True)
             leave = leave[o2]
-            cnt = torch.bincount(own_l, minlength=self.world).tolist() if leave.numel() else [0] * self.world
+            # counts per new owner, exchanged on the device; one host read serves both directions
+            cnt_d = torch.bincount(own_l, minlength=self.world).to(self.comm_device)
+            allc = [torch.zeros_like(cnt_d) for _ in range(self.world)]
+            dist.all_gather(allc, cnt_d)
+            both = torch.stack([cnt_d, torch.stack(allc)[:, self.rank]]).tolist()
+            cnt, recv_counts = both[0], both[1]
             send_idx, o = [], 0
             for p in range(self.world):
                 send_idx.append(None if p == self.rank else leave[o:o + cnt[p]])
                 o += cnt[p]
-            recv_counts = self.ex.counts([0 if ix is None else int(ix.numel()) for ix in send_idx])
             if leave.numel() or sum(recv_counts):
                 got = self._exchange(send_idx, recv_counts, fields)
                 self.stats["migrated"] += int(got.shape[0])
