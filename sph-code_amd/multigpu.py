@@ -122,15 +122,6 @@ class Exchanger:
             if p is not None and float(r[0]) != float(p):
                 raise RuntimeError("halo warm-up: rank %d got %r from rank %d" % (self.rank, float(r[0]), p))
 
-    def counts(self, send_counts):
-        """send_counts (world,) -> recv_counts (world,) (what each peer will send to me)."""
-        if self.world == 1:
-            return [0]
-        mine = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_device)
-        allc = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(allc, mine)
-        return torch.stack(allc)[:, self.rank].tolist()        # one device->host copy, not one per peer
-
     def rows(self, send_bufs, recv_counts, width, dtype=torch.float64, into=None):
         """send_bufs[p]: (count_p, width) tensor for peer p (any device) -> list of received
         (recv_counts[p], width) tensors on the compute device of send_bufs.  `into`: a contiguous
