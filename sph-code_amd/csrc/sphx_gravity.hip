@@ -44,7 +44,13 @@ __global__ __launch_bounds__(GRAV_TILE) void gravity_direct_kernel(int n, const 
             const double dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
             const double r2 = dx * dx + dy * dy + dz * dz + e2;
             // r2^(-3/2); a coincident pair with eps = 0 (r2 == 0) contributes nothing
-            double inv = r2 > 0.0 ? rsqrt(r2) : 0.0;
+            double inv = 0.0;
+            if (r2 > 0.0) {            // hardware seed (2^-26) + two Newton steps: < 1e-15, without the library
+                const double hr = 0.5 * r2;                    // routine's scaling and class checks (r2 is mid-range)
+                double yv = __builtin_amdgcn_rsq(r2);
+                yv = yv * __builtin_fma(-hr * yv, yv, 1.5);
+                inv = yv * __builtin_fma(-hr * yv, yv, 1.5);
+            }
             const double w = q.w * (inv * inv * inv);
             ax += w * dx; ay += w * dy; az += w * dz;
         }
