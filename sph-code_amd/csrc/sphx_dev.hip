@@ -84,7 +84,12 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     SPHX_TRY(sphx_aos_to_soa3(ctx, n, pos, x, y, z));
     double cell_hint = 0.0;
     if (ctx->dev_hmean > 0.0) cell_hint = ctx->cell_factor * ctx->dev_hmean;
-    SPHX_TRY(sphx_build_grid(ctx, n, k, x, y, z, cell_hint));
+    // grid sized from the previous search's box statistics (sphx_grid.hip): the decomposed driver's step
+    // then has ONE host wait - its end-of-step scalars - and the host queues the whole step ahead of the GPU
+    ctx->lag_on = true;
+    const int rc_grid = sphx_build_grid(ctx, n, k, x, y, z, cell_hint);
+    ctx->lag_on = false;
+    SPHX_TRY(rc_grid);
     SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
     hipLaunchKernelGGL(gather3_aos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, ctx->perm.as<int>(), pos, xs, ys, zs, ctx->inv.as<int>());

@@ -256,7 +256,10 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         char* slot = (char*)ctx->pinned + LAG_OFF;
         SPHX_TRY(bbox_launch(ctx, n, x, y, z, true, slot + 512 * cur));
         HIPCHK(hipEventRecord(ctx->lag_bev[cur], ctx->stream));
-        const int use = (ctx->lag_bvalid[prev] && ctx->lag_bn[prev] == n) ? prev : cur;
+        // (the previous statistics describe this cloud if they were taken over about as many particles: the
+        //  fused loop's n is constant, the decomposed driver's owned + ghost count wobbles by a few per cent)
+        const int64_t pn = ctx->lag_bn[prev];
+        const int use = (ctx->lag_bvalid[prev] && pn > 0 && (n > pn ? n - pn : pn - n) * 4 <= n) ? prev : cur;
         HIPCHK(hipEventSynchronize(ctx->lag_bev[use]));
         bbox_finish(slot + 512 * use, bb);
         ctx->lag_bvalid[cur] = true;
