@@ -146,11 +146,18 @@ extern "C" int sphx_dev_prep(sphx_ctx* ctx, const double* pos, const double* vel
                      mu, gamma, ptype);
 }
 
-static int copy_out(sphx_ctx* ctx, double* dst, const DevBuf& src, size_t bytes) {
-    if (!dst) return SPHX_OK;
-    HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    return SPHX_OK;
-}
+// A pass writes its results (already in the caller's order, through the OutMap) into context buffers; for
+// the duration of a sphx_dev_* call the caller's own array stands in for that buffer, so nothing is copied.
+struct Borrow {
+    DevBuf& b;
+    DevBuf saved;
+    Borrow(DevBuf& buf, void* p, size_t bytes) : b(buf), saved(buf) {
+        if (p) { b.p = p; b.cap = bytes; }
+    }
+    ~Borrow() { b = saved; }
+    Borrow(const Borrow&) = delete;
+    Borrow& operator=(const Borrow&) = delete;
+};
 
 extern "C" int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, double* nden,
                                 double* hydro_accel) {
@@ -158,11 +165,8 @@ extern "C" int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, do
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_density before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nb = (size_t)ctx->n * sizeof(double);
+    Borrow b1(ctx->rho, rho, nb), b2(ctx->rhod, rho_dust, nb), b3(ctx->nden, nden, nb), b4(ctx->ha, hydro_accel, 3 * nb);
     SPHX_TRY(sphx_pass_density(ctx, ctx->n, ctx->k));
-    SPHX_TRY(copy_out(ctx, rho, ctx->rho, nb));
-    SPHX_TRY(copy_out(ctx, rho_dust, ctx->rhod, nb));
-    SPHX_TRY(copy_out(ctx, nden, ctx->nden, nb));
-    SPHX_TRY(copy_out(ctx, hydro_accel, ctx->ha, 3 * nb));
     return SPHX_OK;
 }
 
@@ -175,9 +179,10 @@ extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi
     hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        ctx->map_perm, rho_complete, ctx->rho_s.as<double>(), 1);
     HIPCHK(hipGetLastError());
-    SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
-    SPHX_TRY(copy_out(ctx, Pi, ctx->Pi, (size_t)n * sizeof(double)));
-    SPHX_TRY(copy_out(ctx, Bw, ctx->Bw, (size_t)n * sizeof(double)));
+    {
+        Borrow b1(ctx->Pi, Pi, (size_t)n * sizeof(double)), b2(ctx->Bw, Bw, (size_t)n * sizeof(double));
+        SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
+    }
     if (ct_out)   // the positive double whose bits are the minimum (0x7F7F... = none found)
         HIPCHK(hipMemcpyAsync(ct_out, ctx->scal.as<u64>() + SC_CT_BITS, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return SPHX_OK;
@@ -193,9 +198,8 @@ extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const dou
     hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        ctx->map_perm, Bw_complete, ctx->bc_s.as<double>(), 2);
     HIPCHK(hipGetLastError());
+    Borrow b1(ctx->va, visc_accel, 3 * (size_t)n * sizeof(double)), b2(ctx->vh, visc_heat, (size_t)n * sizeof(double));
     SPHX_TRY(sphx_pass_visc(ctx, n, ctx->k, mass));
-    SPHX_TRY(copy_out(ctx, visc_accel, ctx->va, 3 * (size_t)n * sizeof(double)));
-    SPHX_TRY(copy_out(ctx, visc_heat, ctx->vh, (size_t)n * sizeof(double)));
     return SPHX_OK;
 }
 

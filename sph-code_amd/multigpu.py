@@ -246,23 +246,25 @@ class LibBackend:
 
     def density(self):
         n, dev = self.n_total, self.device
-        rho = torch.zeros(n, dtype=torch.float64, device=dev)
-        nden = torch.zeros(n, dtype=torch.float64, device=dev)
-        ha = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        # the passes write every owned particle's entry straight into these (no copy); ghosts' entries are
+        # either filled by the halo exchange (rho, m Pi) or never read
+        rho = torch.empty(n, dtype=torch.float64, device=dev)
+        nden = torch.empty(n, dtype=torch.float64, device=dev)
+        ha = torch.empty((n, 3), dtype=torch.float64, device=dev)
         self._chk(self.lib.sphx_dev_density(self.ctx.h, self._p(rho), None, self._p(nden), self._p(ha)))
         return rho, nden, ha
 
     def pi(self, rho_complete):
         n, dev = self.n_total, self.device
-        bw = torch.zeros(n, dtype=torch.float64, device=dev)
+        bw = torch.empty(n, dtype=torch.float64, device=dev)
         ct = torch.zeros(1, dtype=torch.float64, device=dev)
         self._chk(self.lib.sphx_dev_pi(self.ctx.h, self._p(rho_complete), None, self._p(bw), self._p(ct)))
         return bw, ct
 
     def visc(self, bw_complete, m):
         n, dev = self.n_total, self.device
-        va = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-        vh = torch.zeros(n, dtype=torch.float64, device=dev)
+        va = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        vh = torch.empty(n, dtype=torch.float64, device=dev)
         self._chk(self.lib.sphx_dev_visc(self.ctx.h, self._p(bw_complete), self._p(m), self._p(va), self._p(vh)))
         return va, vh
 
