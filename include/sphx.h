@@ -299,6 +299,15 @@ int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel, int64_t n
  * owned particle i (pos (n,3), w (n): device) - the cells a neighbour of i can lie in.                 */
 int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
                       double g_cs, int G, unsigned char* out);
+/* multigpu.py DistributedSim._replan: w_i = max((halo_scale + skin_frac) h_i, halo_scale h_i + |v_i| dt_last), the
+ * reach an owned particle claims (h, w (n), vel (n,3): device).                                          */
+int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
+                   double skin_frac, double dt_last, double* w);
+/* multigpu.py DistributedSim.step, this rank's end-of-step scalars in one launch: out4 (device) =
+ * { any(h_i + 2 D > w_i) ? 1 : 0,  -(*ct) (ct NULL: untouched),  max h,  mean of the h <= hclip (hclip <= 0: all) }
+ * over the n_owned first entries of h and w_plan.                                                        */
+int sphx_dev_step_scalars(sphx_ctx* ctx, int64_t n_owned, const double* h, const double* w_plan, double D,
+                          double hclip, const double* ct, double* out4);
 int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
                        double* E_internal, double* T, const double* mass, const double* mu,
                        const double* gamma, const double* ptype, const double* hydro_accel,

@@ -440,3 +440,98 @@ extern "C" int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, co
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
+
+// ---- small fused helpers of the decomposed driver (each replaces a dozen tensor-library launches) ------
+// reach claimed by every owned particle (DistributedSim._replan):
+//   w_i = max((halo + skin) h_i, halo h_i + |v_i| dt)
+__global__ __launch_bounds__(256) void reach_kernel(long long n, const double* h, const double* vel, double halo,
+                                                    double skin, double dt, double* w) {
+#pragma clang fp contract(off)          // each operation rounded on its own, as the tensor-library form does
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+    const double speed = sqrt((vx * vx + vy * vy) + vz * vz);
+    const double hi = h[i];
+    w[i] = fmax((halo + skin) * hi, halo * hi + speed * dt);
+}
+extern "C" int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
+                              double skin_frac, double dt_last, double* w) {
+    if (!ctx) return SPHX_E_ARG;
+    if (n < 0) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld", (long long)n);
+    if (n == 0) return SPHX_OK;
+    NEED(h); NEED(vel); NEED(w);
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(reach_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, h, vel,
+                       halo_scale, skin_frac, dt_last, w);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// end-of-step scalars of one rank (DistributedSim.step): out[0] = 1 if any h_i + 2 D > w_i (the halo was too
+// thin), out[1] = -crossing time (*ct, NULL: left alone), out[2] = max h, out[3] = mean of the h <= hclip
+// (hclip <= 0: of all).  One launch; the last block to finish (a ticket that wraps to 0) folds the partials
+// in block order.
+#define SCAL_BLOCKS 256
+__global__ __launch_bounds__(256) void step_scalars_kernel(long long n, const double* h, const double* w, double D2,
+                                                           double hclip, const double* ct, double* partial,
+                                                           unsigned* ticket, double* out) {
+    __shared__ double sm[4][4];
+    __shared__ bool last;
+    double bad = 0.0, hmax = 0.0, hs = 0.0, hc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double hi = h[i];
+        if (hi + D2 > w[i]) bad = 1.0;
+        hmax = fmax(hmax, hi);
+        if (!(hclip > 0.0) || hi <= hclip) { hs += hi; hc += 1.0; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bad = fmax(bad, __shfl_xor(bad, o, 64)); hmax = fmax(hmax, __shfl_xor(hmax, o, 64));
+        hs += __shfl_xor(hs, o, 64); hc += __shfl_xor(hc, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[wv][0] = bad; sm[wv][1] = hmax; sm[wv][2] = hs; sm[wv][3] = hc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* pp = partial + 4 * blockIdx.x;
+        pp[0] = fmax(fmax(sm[0][0], sm[1][0]), fmax(sm[2][0], sm[3][0]));
+        pp[1] = fmax(fmax(sm[0][1], sm[1][1]), fmax(sm[2][1], sm[3][1]));
+        pp[2] = (sm[0][2] + sm[1][2]) + (sm[2][2] + sm[3][2]);
+        pp[3] = (sm[0][3] + sm[1][3]) + (sm[2][3] + sm[3][3]);
+        __threadfence();
+        last = atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double b = 0.0, m = 0.0, s_ = 0.0, c = 0.0;
+        for (unsigned q = 0; q < gridDim.x; ++q) {
+            const double* pp = partial + 4 * q;
+            b = fmax(b, __builtin_nontemporal_load(pp)); m = fmax(m, __builtin_nontemporal_load(pp + 1));
+            s_ += __builtin_nontemporal_load(pp + 2); c += __builtin_nontemporal_load(pp + 3);
+        }
+        out[0] = b;
+        if (ct) out[1] = -*ct;
+        out[2] = m;
+        out[3] = s_ / fmax(c, 1.0);
+    }
+}
+extern "C" int sphx_dev_step_scalars(sphx_ctx* ctx, int64_t n_owned, const double* h, const double* w_plan, double D,
+                                     double hclip, const double* ct, double* out4) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(out4);
+    if (n_owned < 1) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_step_scalars: n_owned=%lld", (long long)n_owned);
+    NEED(h); NEED(w_plan);
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool fresh = ctx->scal_tmp.p == nullptr;
+    SPHX_TRY(sphx_ensure(ctx, ctx->scal_tmp, (size_t)(4 * SCAL_BLOCKS + 2) * sizeof(double)));
+    double* partial = ctx->scal_tmp.as<double>();
+    unsigned* ticket = reinterpret_cast<unsigned*>(partial + 4 * SCAL_BLOCKS);
+    if (fresh) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(double), ctx->stream));
+    int blocks = (int)((n_owned + 255) / 256);
+    if (blocks > SCAL_BLOCKS) blocks = SCAL_BLOCKS;
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (long long)n_owned, h, w_plan,
+                       2.0 * D, hclip, ct, partial, ticket, out4);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

@@ -159,6 +159,7 @@ struct sphx_ctx {
     int64_t nbr_api_n = 0;
     int nbr_api_k = 0;
     bool ct_primed = false;             // SC_CT_BITS holds "none yet" (left so by dt_kernel)
+    DevBuf scal_tmp;                    // step_scalars_kernel's per-block partials + its ticket
     DevBuf hsum_tmp;                    // hsum_kernel's per-block partial sums + its ticket
     int exp_knn = -1, exp_blob = 0, exp_pass = -1;
     size_t exp_blob_lds = 0;

@@ -225,6 +225,21 @@ class LibBackend:
                                              self._p(w.contiguous()), lo, float(g_cs), int(G), self._p(out)))
         return out
 
+    def reach(self, h, vel, halo_scale, skin_frac, dt_last):
+        """w_i = max((halo + skin) h_i, halo h_i + |v_i| dt) in one launch (sphx_dev_reach)."""
+        w = torch.empty_like(h)
+        self._chk(self.lib.sphx_dev_reach(self.ctx.h, int(h.shape[0]), self._p(h.contiguous()), self._p(vel.contiguous()),
+                                          float(halo_scale), float(skin_frac), float(dt_last), self._p(w)))
+        return w
+
+    def step_scalars(self, n_owned, h, w_plan, D, hclip, ct):
+        """(4,) device tensor {halo too thin?, -crossing time, max h, clipped mean h} in one launch
+        (sphx_dev_step_scalars)."""
+        out = torch.empty(4, dtype=torch.float64, device=self.device)
+        self._chk(self.lib.sphx_dev_step_scalars(self.ctx.h, int(n_owned), self._p(h), self._p(w_plan), float(D),
+                                                 float(hclip), self._p(ct), self._p(out)))
+        return out
+
     def search(self, pos, n_owned, hint, mean_h):
         n = pos.shape[0]
         self.n_total = n
@@ -500,16 +515,20 @@ class DistributedSim:
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
         # (a radius changes by at most twice the local displacement, so fast movers claim more)
-        speed = torch.sqrt((s["vel"] * s["vel"]).sum(dim=1))
-        self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"],
-                                    self.halo_scale * s["h"] + speed * self.dt_last)
+        if hasattr(self.backend, "reach") and self.n_owned:
+            self.w_plan = self.backend.reach(s["h"], s["vel"], self.halo_scale, self.skin_frac, self.dt_last)
+        else:
+            speed = torch.sqrt((s["vel"] * s["vel"]).sum(dim=1))
+            self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"],
+                                        self.halo_scale * s["h"] + speed * self.dt_last)
         if self.world > 1:
             self.send_idx, self.recv_counts = self._plan(self.w_plan)
         else:
             self.send_idx, self.recv_counts = [None], [0]
         parts = [ix for ix in self.send_idx if ix is not None and ix.numel()]
         self.send_cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=self.device)
-        self.pos_plan = s["pos"].clone()
+        # (positions at plan time: only read by the staleness check, which forced replanning skips)
+        self.pos_plan = s["pos"].clone() if self.force_replan <= 0 else None
         self.stats["replans"] = self.stats.get("replans", 0) + 1
 
     def _cell_order(self):
@@ -551,6 +570,8 @@ class DistributedSim:
                 self._replan()
             D = 0.0
         else:
+            if self.pos_plan is None:              # (the last plan was a forced one: nothing to compare with)
+                self.pos_plan = s["pos"].clone()
             with self._sec("stale_check"):
                 if no:
                     d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
@@ -582,9 +603,11 @@ class DistributedSim:
             with self._sec("search"):
                 h = be.search(pos, no, hint, mean_h)
             f64 = dict(dtype=torch.float64, device=h.device)
+            fused = hasattr(be, "step_scalars") and no > 0
             # a kNN radius that outgrew its claimed reach (checked below, together with dt: the sums
             # are run on the assumption that the halo was sufficient, which it nearly always is)
-            bad_t = (h[:no] + 2.0 * D > self.w_plan).any().to(torch.float64).reshape(1) if no else torch.zeros(1, **f64)
+            if not fused:
+                bad_t = (h[:no] + 2.0 * D > self.w_plan).any().to(torch.float64).reshape(1) if no else torch.zeros(1, **f64)
             # ---- halo phases 2-4: 8 B per ghost, received straight into the tail of the (n_total,)
             # array the library just filled for the owned particles ----------------------------
             tail = lambda a: a[no:].view(ng, 1)
@@ -600,22 +623,30 @@ class DistributedSim:
             # minimum crossing time for dt (nsc:786, drv:222-229; as max of the negative), max / mean h
             t_dt = time.perf_counter()
             ctt = ct.reshape(-1)[:1].to(**f64) if torch.is_tensor(ct) else torch.tensor([float(ct)], **f64)
-            red = torch.cat([bad_t, -ctt])
-            if self.world > 1:
-                red = red.to(self.comm_device)
-                dist.all_reduce(red, op=dist.ReduceOp.MAX)
-                red = red.to(h.device)
-            if no:
-                ho = h[:no]
-                if self.hmean_prev > 0.0:          # escapers' radii must not size the cells (robust mean)
-                    keep = ho <= 8.0 * self.hmean_prev
-                    hm = (ho * keep).sum() / keep.sum().clamp(min=1)
-                else:
-                    hm = ho.mean()
-                loc = torch.stack([ho.max(), hm])
+            if fused:                              # one launch: {verdict, -ct, max h, robust mean h}
+                out4 = be.step_scalars(no, h, self.w_plan, D, 8.0 * self.hmean_prev if self.hmean_prev > 0.0 else 0.0,
+                                       ctt)
+                red, loc = out4[:2], out4[2:]
             else:
-                loc = torch.zeros(2, **f64)
-            vals = torch.cat([red, loc]).tolist()
+                red = torch.cat([bad_t, -ctt])
+                if no:
+                    ho = h[:no]
+                    if self.hmean_prev > 0.0:          # escapers' radii must not size the cells (robust mean)
+                        keep = ho <= 8.0 * self.hmean_prev
+                        hm = (ho * keep).sum() / keep.sum().clamp(min=1)
+                    else:
+                        hm = ho.mean()
+                    loc = torch.stack([ho.max(), hm])
+                else:
+                    loc = torch.zeros(2, **f64)
+            if self.world > 1:
+                if red.device == self.comm_device:
+                    dist.all_reduce(red, op=dist.ReduceOp.MAX)          # (in place: a view of out4 when fused)
+                else:
+                    red = red.to(self.comm_device)
+                    dist.all_reduce(red, op=dist.ReduceOp.MAX)
+                    red = red.to(h.device)
+            vals = out4.tolist() if (fused and red.data_ptr() == out4.data_ptr()) else torch.cat([red, loc]).tolist()
             if vals[0] < 0.5:
                 break
             # the halo was too thin somewhere: those particles claim their new radius (x1.5), everybody

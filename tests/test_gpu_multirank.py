@@ -164,3 +164,37 @@ def test_need_map_kernel_matches_tensor_form():
         assert torch.equal(a, b), int((a != b).sum())
     assert 0 < int(sim(be, pos[8:], w[8:]).sum()) < G ** 3      # a non-trivial map
     torch.cuda.synchronize()
+
+
+def test_fused_reach_and_step_scalars_match_tensor_forms():
+    """sphx_dev_reach / sphx_dev_step_scalars (one launch each) against the tensor-library expressions of
+    DistributedSim._replan / .step that the CPU tests run."""
+    import torch
+    from sph_code_amd.multigpu import LibBackend
+    be = LibBackend(0, k=8)
+    dev = be.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, no = 70000, 65537
+    h = (torch.rand(n, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    h[17] = 40.0                                      # an escaper's radius: left out of the robust mean
+    vel = torch.randn((n, 3), generator=g, dtype=torch.float64).to(dev)
+    halo, skin, dt = 1.15, 0.15, 0.37
+    w = be.reach(h, vel, halo, skin, dt)
+    speed = torch.sqrt((vel * vel).sum(dim=1))
+    w_ref = torch.maximum((halo + skin) * h, halo * h + speed * dt)
+    assert float(((w - w_ref).abs() / w_ref).max()) <= 4e-16      # (the same expression, to rounding)
+    ct = torch.tensor([3.25], dtype=torch.float64, device=dev)
+    for D, hmean_prev in ((0.0, 1.0), (0.02, 1.0), (0.4, 0.0)):
+        hclip = 8.0 * hmean_prev if hmean_prev > 0 else 0.0
+        out = be.step_scalars(no, h, w, D, hclip, ct).tolist()
+        ho = h[:no]
+        bad = float((ho + 2.0 * D > w[:no]).any())
+        if hmean_prev > 0:
+            keep = ho <= hclip
+            hm = float((ho * keep).sum() / keep.sum().clamp(min=1))
+        else:
+            hm = float(ho.mean())
+        assert out[0] == bad and out[1] == -3.25 and out[2] == float(ho.max())
+        assert abs(out[3] - hm) <= 1e-13 * hm
+    assert be.step_scalars(no, h, w, 0.0, 8.0, ct).tolist()[0] == 0.0 and be.step_scalars(no, h, w, 0.4, 8.0, ct).tolist()[0] == 1.0
+    torch.cuda.synchronize()
