@@ -502,18 +502,28 @@ __global__ __launch_bounds__(256) void step_scalars_kernel(long long n, const do
         last = atomicInc(ticket, gridDim.x - 1) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
+    if (last) {                                    // (the whole block or none of it) one partial per thread,
+        __threadfence();                           // then the same fixed tree as above
         double b = 0.0, m = 0.0, s_ = 0.0, c = 0.0;
-        for (unsigned q = 0; q < gridDim.x; ++q) {
+        for (unsigned q = threadIdx.x; q < gridDim.x; q += blockDim.x) {
             const double* pp = partial + 4 * q;
             b = fmax(b, __builtin_nontemporal_load(pp)); m = fmax(m, __builtin_nontemporal_load(pp + 1));
             s_ += __builtin_nontemporal_load(pp + 2); c += __builtin_nontemporal_load(pp + 3);
         }
-        out[0] = b;
-        if (ct) out[1] = -*ct;
-        out[2] = m;
-        out[3] = s_ / fmax(c, 1.0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            b = fmax(b, __shfl_xor(b, o, 64)); m = fmax(m, __shfl_xor(m, o, 64));
+            s_ += __shfl_xor(s_, o, 64); c += __shfl_xor(c, o, 64);
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sm[wv][0] = b; sm[wv][1] = m; sm[wv][2] = s_; sm[wv][3] = c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            out[0] = fmax(fmax(sm[0][0], sm[1][0]), fmax(sm[2][0], sm[3][0]));
+            if (ct) out[1] = -*ct;
+            out[2] = fmax(fmax(sm[0][1], sm[1][1]), fmax(sm[2][1], sm[3][1]));
+            out[3] = ((sm[0][2] + sm[1][2]) + (sm[2][2] + sm[3][2])) / fmax((sm[0][3] + sm[1][3]) + (sm[2][3] + sm[3][3]), 1.0);
+        }
     }
 }
 extern "C" int sphx_dev_step_scalars(sphx_ctx* ctx, int64_t n_owned, const double* h, const double* w_plan, double D,
