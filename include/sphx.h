@@ -299,6 +299,16 @@ int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel, int64_t n
  * owned particle i (pos (n,3), w (n): device) - the cells a neighbour of i can lie in.                 */
 int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
                       double g_cs, int G, unsigned char* out);
+/* sphx_dev_integrate with the step's verdict and dt taken on the device: red2 (device) = {1 if some rank's halo
+ * was too thin, -(global minimum crossing time)}, the driver's one reduction.  red2[0] > 0.5: nothing is changed
+ * (the step is redone) and *dt_out = 0; otherwise dt follows drv:222-229 (first, fixed_dt as in sphx_step) and
+ * is written to dt_out (device).  The host reads verdict and dt after launching this: no round trip between
+ * the sums and the update.                                                                                */
+int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                            double* E_internal, double* T, const double* mass, const double* mu,
+                            const double* gamma, const double* ptype, const double* hydro_accel,
+                            const double* visc_accel, const double* visc_heat, const double* red2,
+                            int first, double fixed_dt, double* dt_out);
 /* multigpu.py DistributedSim._replan: w_i = max((halo_scale + skin_frac) h_i, halo_scale h_i + |v_i| dt_last), the
  * reach an owned particle claims (h, w (n), vel (n,3): device).                                          */
 int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,

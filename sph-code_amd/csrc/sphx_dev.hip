@@ -215,11 +215,32 @@ struct DevIntegArgs {
     double *pos, *vel, *acc, *E, *T;
     const double *m, *mu, *gam, *ptype, *ha, *va, *vh;
     double dt, m_h, kB, lim;
+    // device-side verdict and dt (sphx_dev_integrate_auto): red2 = {halo too thin?, -min crossing time}
+    const double* red2;
+    double* dt_out;
+    int first;
+    double fixed_dt, dt_0, max_age;
 };
 __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const double dt = a.dt;
+    double dt = a.dt;
+    if (a.red2) {
+        if (a.red2[0] > 0.5) {                    // the halo was too thin somewhere: the step will be redone
+            if (i == 0) *a.dt_out = 0.0;
+            return;
+        }
+        const double ct_min = -a.red2[1];
+        const double huge = __longlong_as_double(0x7F7F7F7F7F7F7F7Fll);                 // "no gas particle voted"
+        const double ctv = (ct_min >= huge) ? a.dt_0 / 10.0 : ct_min + 0.0001;         // nsc:783-786
+        if (a.fixed_dt > 0.0) {
+            dt = a.fixed_dt;
+        } else {
+            dt = a.first ? a.dt_0 / 10.0 : fmax(a.dt_0 / 5.0, fmin(a.dt_0 * 2.0, ctv));   // drv:223-226
+            if (ctv > a.max_age) dt = a.max_age / 100.0;                                // drv:228-229
+        }
+        if (i == 0) *a.dt_out = dt;
+    }
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     double v[3], pa[3], vis[3];
 #pragma unroll
@@ -283,6 +304,34 @@ extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, d
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
+    a.red2 = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
+    hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// The same update with the step's verdict and dt taken on the device: red2 (device) = {1 if some rank's halo
+// was too thin, -(global minimum crossing time)} as the driver's one reduction left it.  Nothing is
+// changed when red2[0] > 0.5 (the driver redoes the step); otherwise dt follows drv:222-229 and is written
+// to dt_out (device).  The host can read verdict and dt AFTER launching this - no round trip in between.
+extern "C" int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                                       double* E_internal, double* T, const double* mass, const double* mu,
+                                       const double* gamma, const double* ptype, const double* hydro_accel,
+                                       const double* visc_accel, const double* visc_heat, const double* red2,
+                                       int first, double fixed_dt, double* dt_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel); NEED(accel_old); NEED(E_internal); NEED(T); NEED(mass); NEED(mu); NEED(gamma);
+    NEED(ptype); NEED(hydro_accel); NEED(visc_accel); NEED(visc_heat); NEED(red2); NEED(dt_out);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n_owned < 1) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_integrate_auto: n_owned=%lld", (long long)n_owned);
+    DevIntegArgs a;
+    a.n = (int)n_owned;
+    a.pos = pos; a.vel = vel; a.acc = accel_old; a.E = E_internal; a.T = T;
+    a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
+    a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
+    a.dt = 0.0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
+    a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
+    a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;

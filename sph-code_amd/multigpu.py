@@ -283,6 +283,16 @@ class LibBackend:
         self._chk(self.lib.sphx_dev_visc(self.ctx.h, self._p(bw_complete), self._p(m), self._p(va), self._p(vh)))
         return va, vh
 
+    def integrate_auto(self, n_owned, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, red2, first, fixed_dt):
+        """Leapfrog with verdict and dt taken on the device (sphx_dev_integrate_auto) -> dt as a (1,) device tensor
+        (0 when the verdict says the step must be redone: nothing was changed then)."""
+        dt = torch.empty(1, dtype=torch.float64, device=self.device)
+        self._chk(self.lib.sphx_dev_integrate_auto(self.ctx.h, n_owned, self._p(pos), self._p(vel), self._p(acc),
+                                                   self._p(E), self._p(T), self._p(m), self._p(mu), self._p(gam),
+                                                   self._p(ptype), self._p(ha), self._p(va), self._p(vh),
+                                                   self._p(red2), 1 if first else 0, float(fixed_dt), self._p(dt)))
+        return dt
+
     def integrate(self, n_owned, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
         self._chk(self.lib.sphx_dev_integrate(self.ctx.h, n_owned, self._p(pos), self._p(vel), self._p(acc),
                                               self._p(E), self._p(T), self._p(m), self._p(mu), self._p(gam),
@@ -646,7 +656,16 @@ class DistributedSim:
                     red = red.to(self.comm_device)
                     dist.all_reduce(red, op=dist.ReduceOp.MAX)
                     red = red.to(h.device)
-            vals = out4.tolist() if (fused and red.data_ptr() == out4.data_ptr()) else torch.cat([red, loc]).tolist()
+            auto = fused and hasattr(be, "integrate_auto")
+            if auto:
+                # the update is launched before the host learns the verdict: the kernel itself leaves the state
+                # alone when the step has to be redone, and works out dt from the reduced crossing time
+                red_dev = red if red.device == h.device else red.to(h.device)
+                dt_t = be.integrate_auto(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"],
+                                         s["ptype"], ha, va, vh, red_dev.contiguous(), self.first, fixed_dt)
+                vals = torch.cat([red_dev, loc, dt_t]).tolist()
+            else:
+                vals = out4.tolist() if (fused and red.data_ptr() == out4.data_ptr()) else torch.cat([red, loc]).tolist()
             if vals[0] < 0.5:
                 break
             # the halo was too thin somewhere: those particles claim their new radius (x1.5), everybody
@@ -659,15 +678,18 @@ class DistributedSim:
             D = 0.0
             self.stats["redo"] += 1
         ct_min, self.hmax_prev, self.hmean_prev = -vals[1], vals[2], vals[3]
-        ctv = self.DT_0 / 10. if ct_min >= HUGE_CT else ct_min + 0.0001
-        if fixed_dt > 0:
-            dt = fixed_dt
+        if auto:
+            dt = vals[4]                                   # (worked out and applied on the device)
         else:
-            dt = self.DT_0 / 10. if self.first else max(self.DT_0 / 5., min(self.DT_0 * 2., ctv))
-            if ctv > self.MAX_AGE:
-                dt = self.MAX_AGE / 100.
-        be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
-                     ha, va, vh, dt)
+            ctv = self.DT_0 / 10. if ct_min >= HUGE_CT else ct_min + 0.0001
+            if fixed_dt > 0:
+                dt = fixed_dt
+            else:
+                dt = self.DT_0 / 10. if self.first else max(self.DT_0 / 5., min(self.DT_0 * 2., ctv))
+                if ctv > self.MAX_AGE:
+                    dt = self.MAX_AGE / 100.
+            be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
+                         ha, va, vh, dt)
         self.host_ms["dt+integrate"] = self.host_ms.get("dt+integrate", 0.0) + (time.perf_counter() - t_dt) * 1e3
         s["h"] = h[:no].contiguous()
         self.last = dict(rho=rho[:no], nden=nden[:no], visc_heat=vh[:no])

@@ -198,3 +198,50 @@ def test_fused_reach_and_step_scalars_match_tensor_forms():
         assert abs(out[3] - hm) <= 1e-13 * hm
     assert be.step_scalars(no, h, w, 0.0, 8.0, ct).tolist()[0] == 0.0 and be.step_scalars(no, h, w, 0.4, 8.0, ct).tolist()[0] == 1.0
     torch.cuda.synchronize()
+
+
+def test_integrate_auto_takes_verdict_and_dt_on_the_device():
+    """sphx_dev_integrate_auto: with the verdict flag set nothing moves (the driver redoes the step); otherwise
+    it is sphx_dev_integrate with dt from the reduced crossing time by the driver's rule (drv:222-229)."""
+    import torch
+    from sph_code_amd.multigpu import LibBackend, DistributedSim, HUGE_CT
+    be = LibBackend(0, k=8)
+    dev = be.device
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n = 5000
+    r = lambda *s_: torch.rand(s_, generator=g, dtype=torch.float64).to(dev)
+    base = dict(pos=r(n, 3) * 1e17, vel=r(n, 3) * 1e3, acc=r(n, 3) * 1e-12, E=r(n) * 1e30 + 1e30, T=r(n) * 10 + 10,
+                m=r(n) * 1e30 + 1e30, mu=r(n) + 1, gam=r(n) * 0.3 + 1.3, ptype=(r(n) > 0.8).to(torch.float64) * 2.0)
+    ha, va, vh = r(n, 3) * 1e-12, r(n, 3) * 1e-13, r(n) * 1e10
+    DT0, MAXAGE = DistributedSim.DT_0, DistributedSim.MAX_AGE
+
+    def rule(ct, first, fixed):
+        ctv = DT0 / 10. if ct >= HUGE_CT else ct + 0.0001
+        if fixed > 0:
+            return fixed
+        dt = DT0 / 10. if first else max(DT0 / 5., min(DT0 * 2., ctv))
+        return MAXAGE / 100. if ctv > MAXAGE else dt
+
+    def run(auto, bad, ct, first, fixed):
+        s_ = {k_: v.clone() for k_, v in base.items()}
+        args = (n, s_["pos"], s_["vel"], s_["acc"], s_["E"], s_["T"], s_["m"], s_["mu"], s_["gam"], s_["ptype"], ha, va, vh)
+        if auto:
+            red2 = torch.tensor([bad, -ct], dtype=torch.float64, device=dev)
+            dt = float(be.integrate_auto(*args, red2, first, fixed)[0])
+        else:
+            dt = rule(ct, first, fixed)
+            be.integrate(*args, dt)
+        return s_, dt
+
+    for ct, first, fixed in ((DT0 * 0.7, False, 0.0), (DT0 * 0.01, False, 0.0), (DT0 * 50, False, 0.0), (HUGE_CT, False, 0.0),
+                             (DT0 * 0.7, True, 0.0), (DT0 * 0.7, False, 12345.0), (MAXAGE * 2, False, 0.0)):
+        a, dta = run(True, 0.0, ct, first, fixed)
+        b, dtb = run(False, 0.0, ct, first, fixed)
+        assert dta == dtb, (ct, first, fixed, dta, dtb)
+        for k_ in ("pos", "vel", "acc", "E", "T"):
+            assert torch.equal(a[k_], b[k_]), k_
+    frozen, dt0 = run(True, 1.0, DT0 * 0.7, False, 0.0)
+    assert dt0 == 0.0
+    for k_ in ("pos", "vel", "acc", "E", "T"):
+        assert torch.equal(frozen[k_], base[k_]), k_
+    torch.cuda.synchronize()
