@@ -194,6 +194,27 @@ int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, const double
                     double solar_mass, double* dust_out /* (n,nspecies) */,
                     double* gas_out /* (n,nspecies) */);
 
+/* ---- the driver's inline integrator statements as array functions ----------------------- *
+ * The reference has no function for these: they are straight-line statements inside its time
+ * loop.  Each entry replaces the cited block on host arrays; the device code is the one the fused
+ * step loop runs (sphx_leapfrog.h).  Pinned by tests/golden/driver_integrator.npz.          */
+/* code_running.py:223-229: dt[i] from crossing time ct[i] (nsc.crossing_time's return value) and
+ * first[i] (age == 0): dt_0/10 | max(dt_0/5, min(2 dt_0, ct)); ct > MAX_AGE -> MAX_AGE/100.   */
+int sphx_dt_rule(sphx_ctx* ctx, int64_t n, const double* ct, const int32_t* first, double* dt);
+/* code_running.py:233-238: |x| <= 1e11 AU, nan_to_num on points and velocities ((n,3), in place) */
+int sphx_clamp_arrays(sphx_ctx* ctx, int64_t n, double* points, double* velocities);
+/* code_running.py:460-491: pressure_accel = delp/rho [gas]; visc = drag_on_gas rho_dust/rho [gas] +
+ * drag_reaction + av_accel (drag pointers NULL: av_accel alone); limiter (:475); total = grav +
+ * pressure + visc (grav NULL: none); points += total dt^2/2 + v dt; v += (total + old)/2 dt
+ * (old_accel NULL: shapes differ, dv = total dt, :484-485); E += av_heat dt; T = E mu m_h/(gamma m k).
+ * In place: points, velocities (n,3), E_internal (n,); out: total_accel (n,3), T (n,).        */
+int sphx_leapfrog(sphx_ctx* ctx, int64_t n, double* points, double* velocities, double* total_accel,
+                  const double* old_accel, double* E_internal, double* T, const double* mass,
+                  const double* mu, const double* gamma, const double* ptype, const double* grav_accel,
+                  const double* delp, const double* densities, const double* dust_densities,
+                  const double* drag_on_gas, const double* drag_reaction, const double* av_accel,
+                  const double* av_heat, double dt);
+
 /* ---- device-resident simulation state: the fused hot path of drv:217-491 ------------- *
  * upload once, step many times (search -> dt -> sums -> leapfrog, nothing leaves HBM),
  * download when needed.  Particle order on the device changes every step (cell sort);
@@ -276,7 +297,7 @@ int sphx_dev_prep(sphx_ctx* ctx, const double* pos, const double* vel, const dou
 /* nsc:588-619; outputs (n_total,) / (n_total,3), any may be NULL                            */
 int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, double* nden, double* hydro_accel);
 /* nsc:639-649 + nsc:776-786; rho_complete (n_total); ct_out: device double = min crossing
- * time over the owned gas particles, or 0x7F7F7F7F7F7F7F7F (~1.4e306) when there is none     */
+ * time over the owned gas particles, or +inf when there is none (votes are at most DBL_MAX)  */
 int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi, double* Bw, double* ct_out);
 /* nsc:651-654; Bw_complete (n_total) = m Pi [t==0]; mass (n_total)                           */
 int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const double* mass, double* visc_accel,

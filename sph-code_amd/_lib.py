@@ -55,6 +55,9 @@ SIGNATURES = {
     "sphx_net_impulse": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D, _D, _D, _D, _I, _D, _D, _D, _D]),
     "sphx_agb_yields": (C.c_int, [_P, C.c_int64, _D, _D, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D, _D, _D,
                                   C.POINTER(C.c_int32), C.c_double, C.c_int, _D, _D, C.c_double, _D, _D]),
+    "sphx_dt_rule": (C.c_int, [_P, C.c_int64, _D, C.POINTER(C.c_int32), _D]),
+    "sphx_clamp_arrays": (C.c_int, [_P, C.c_int64, _D, _D]),
+    "sphx_leapfrog": (C.c_int, [_P, C.c_int64] + [_D] * 18 + [C.c_double]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
     "sphx_state_set_loop_forms": (C.c_int, [_P, C.c_int, C.c_double]),

@@ -1,15 +1,22 @@
-"""Build libsphx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libsphx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every .hip source is compiled to its own object (in parallel, rebuilt only when it or a header is
+newer) and the objects are linked into sph-code_amd/libsphx.so."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libsphx.so")
-SOURCES = ["sphx_api.hip", "sphx_grid.hip", "sphx_knn.hip", "sphx_sums.hip", "sphx_integrate.hip",
-           "sphx_loopforms.hip", "sphx_dev.hip", "sphx_refresh.hip", "sphx_blob.hip", "sphx_agb.hip", "sphx_gravity.hip"]
-HEADERS = [os.path.join(CSRC, "sphx_internal.h"), os.path.join(CSRC, "sphx_wave.h"),
+SOURCES = ["sphx_api.hip", "sphx_grid.hip", "sphx_knn.hip", "sphx_knn_group.hip", "sphx_sums.hip",
+           "sphx_integrate.hip", "sphx_loopforms.hip", "sphx_dev.hip", "sphx_refresh.hip", "sphx_blob.hip",
+           "sphx_agb.hip", "sphx_gravity.hip"]
+HEADERS = [os.path.join(CSRC, "sphx_internal.h"), os.path.join(CSRC, "sphx_wave.h"), os.path.join(CSRC, "sphx_blob.h"), os.path.join(CSRC, "sphx_leapfrog.h"),
            os.path.join(os.path.dirname(HERE), "include", "sphx.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def hipcc_path():
@@ -19,29 +26,67 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libsphx.so cannot be built (set HIPCC=/path/to/hipcc)")
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _flag_stamp(extra):
+    return " ".join(FLAGS + extra)
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in _sources()] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(hipcc, src, obj, extra, verbose):
+    cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj + ".tmp", src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
+    os.replace(obj + ".tmp", obj)
+    return res.stderr
 
 
 def build(force=False, verbose=False):
     """Compile every HIP source into sph-code_amd/libsphx.so.  Returns the library path."""
     if not force and not needs_build():
         return LIB
+    hipcc = hipcc_path()
     extra = os.environ.get("SPHX_EXTRA_FLAGS", "").split()
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + \
-          ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    stamp_file = os.path.join(OBJ, "flags.txt")
+    same_flags = os.path.exists(stamp_file) and open(stamp_file).read() == _flag_stamp(extra)
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS)
+    jobs, objs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        stale = force or not same_flags or not os.path.exists(obj) or \
+            os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
+        if stale:
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for warn in ex.map(lambda j: _compile(hipcc, j[0], j[1], extra, verbose), jobs):
+            if verbose and warn.strip():
+                print(warn)
+    open(stamp_file, "w").write(_flag_stamp(extra))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -102,16 +102,24 @@ def _with_nb(neighbor, nb, call):
     _nb_held = neighbor if reusable else None
 
 
+def _mrn_limits(mrn_constants):
+    lo, hi = float(mrn_constants[0]), float(mrn_constants[1])        # grain radii a_min, a_max
+    return lo, hi
+
+
 def grain_mass(mineral_densities=mineral_densities, mrn_constants=mrn_constants):
-    """nsc:76-79 (host-side constant table)."""
-    return mineral_densities * -np.diff(mrn_constants ** 0.5) / np.diff(mrn_constants ** -2.5) \
-        * (4. / 5.) * 4 * np.pi / 3.
+    """Mean grain mass per species for the MRN size law n(a) ~ a^-3.5 (the table nsc:76-79 builds):
+    rho 4 pi/3 <a^3>, with <a^3> = (4/5) (a_max^0.5 - a_min^0.5) / (a_min^-2.5 - a_max^-2.5)."""
+    lo, hi = _mrn_limits(mrn_constants)
+    ratio = -(hi ** 0.5 - lo ** 0.5) / (hi ** -2.5 - lo ** -2.5)
+    return mineral_densities * ratio * (4. / 5.) * 4 * np.pi / 3.
 
 
 def sigma_effective(mineral_densities=mineral_densities, mrn_constants=mrn_constants, mu_specie=mu_specie):
-    """nsc:69-74 (host-side constant table)."""
-    return mu_specie * amu / mineral_densities * (3. / 4.) \
-        * -np.diff(mrn_constants ** -0.5) / np.diff(mrn_constants ** 0.5)
+    """Effective cross-section per species for the same size law (the table nsc:69-74 builds)."""
+    lo, hi = _mrn_limits(mrn_constants)
+    ratio = -(hi ** -0.5 - lo ** -0.5) / (hi ** 0.5 - lo ** 0.5)
+    return mu_specie * amu / mineral_densities * (3. / 4.) * ratio
 
 
 # ==============================================================================================
@@ -279,3 +287,55 @@ def grav_force_tree(mass, points, sizes, G=6.67430e-11, ws=1, order=2):
     finally:
         c.lib.sphx_set_gravity_order(c.h, 2)
     return out
+
+
+# ==============================================================================================
+# The driver's inline integrator statements (the reference has no function for them)
+# ==============================================================================================
+MAX_AGE = 3e7 * year            # drv:78
+
+
+def timestep(ct, first):
+    """drv:223-229: dt from the crossing time (`first` = the driver's `age == 0`)."""
+    c = context()
+    c.set_constants(dt_0=float(dt_0), max_age=float(MAX_AGE))
+    cts = np.array([ct], dtype=np.float64)
+    fl = np.array([1 if first else 0], dtype=np.int32)
+    out = np.empty(1)
+    c.check(c.lib.sphx_dt_rule(c.h, 1, dp(cts), fl.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int32)), dp(out)))
+    return float(out[0])
+
+
+def clamp_state(points, velocities):
+    """drv:233-238 -> (points, velocities) clamped to |x| <= 1e11 AU and nan_to_num'ed (new arrays)."""
+    p = np.array(points, dtype=np.float64, order="C")
+    v = np.array(velocities, dtype=np.float64, order="C")
+    c = context()
+    c.check(c.lib.sphx_clamp_arrays(c.h, p.shape[0], dp(p), dp(v)))
+    return p, v
+
+
+def leapfrog(points, velocities, total_accel, E_internal, mass, mu_array, gamma_array, particle_type, delp,
+             densities, av, dt, grav_accel=None, dust_densities=None, viscous_drag=None):
+    """drv:460-491 with the driver's variable names: `av` = nsc.artificial_viscosity's (accel, heat),
+    `viscous_drag` = nsc.net_impulse's (onto_gas, reaction) or None, `total_accel` = the previous step's (None or a
+    different shape: dv = a dt, drv:484-485).  -> (points, velocities, total_accel, E_internal, T), new arrays."""
+    p = np.array(points, dtype=np.float64, order="C")
+    n = p.shape[0]
+    v = np.array(velocities, dtype=np.float64, order="C")
+    E = np.array(E_internal, dtype=np.float64, order="C")
+    old = None if total_accel is None or np.shape(total_accel) != (n, 3) else f64(total_accel, (n, 3))
+    tot = np.empty((n, 3)); T = np.empty(n)
+    m, mu, gam, pt = f64(mass, (n,)), f64(mu_array, (n,)), f64(gamma_array, (n,)), f64(particle_type, (n,))
+    G, rho = f64(delp, (n, 3)), f64(densities, (n,))
+    ava, avh = f64(av[0], (n, 3)), f64(av[1], (n,))
+    gr = None if grav_accel is None else f64(grav_accel, (n, 3))
+    rd = None if dust_densities is None else f64(dust_densities, (n,))
+    don = dre = None
+    if viscous_drag is not None:
+        don, dre = f64(viscous_drag[0], (n, 3)), f64(viscous_drag[1], (n, 3))
+    c = context()
+    c.set_constants(k_B=k, m_h=m_h)
+    c.check(c.lib.sphx_leapfrog(c.h, n, dp(p), dp(v), dp(tot), dp(old), dp(E), dp(T), dp(m), dp(mu), dp(gam), dp(pt),
+                                dp(gr), dp(G), dp(rho), dp(rd), dp(don), dp(dre), dp(ava), dp(avh), float(dt)))
+    return p, v, tot, E, T

@@ -363,6 +363,8 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
         ctx->s = s;
     }
     HIPCHK(hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream));
+    ctx->ct_primed = false;       // SC_CT_BITS was just zeroed: the next pass 2 must prime it again
+    ctx->nbr_api_valid = false;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->n = n;
     ctx->npad = sphx_pad64(n);
@@ -436,6 +438,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
+    ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
     HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238
     SPHX_TRY(sphx_clamp(ctx, n, ctx->st));

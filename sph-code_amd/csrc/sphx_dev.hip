@@ -11,6 +11,7 @@
 #include "sphx_internal.h"
 #pragma clang fp contract(off)
 #include <float.h>
+#include "sphx_leapfrog.h"
 
 extern "C" int sphx_set_stream(sphx_ctx* ctx, void* stream) {
     if (!ctx) return SPHX_E_ARG;
@@ -183,7 +184,7 @@ extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi
         Borrow b1(ctx->Pi, Pi, (size_t)n * sizeof(double)), b2(ctx->Bw, Bw, (size_t)n * sizeof(double));
         SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
     }
-    if (ct_out)   // the positive double whose bits are the minimum (0x7F7F... = none found)
+    if (ct_out)   // the positive double whose bits are the minimum (+inf = none found)
         HIPCHK(hipMemcpyAsync(ct_out, ctx->scal.as<u64>() + SC_CT_BITS, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return SPHX_OK;
 }
@@ -204,12 +205,7 @@ extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const dou
 }
 
 // ---- drv:460-491 on caller-order (n,3) arrays, owned particles only ---------------------------
-__device__ __forceinline__ double nan_to_num_v(double v) {
-    if (v != v) return 0.0;
-    if (v > DBL_MAX) return DBL_MAX;
-    if (v < -DBL_MAX) return -DBL_MAX;
-    return v;
-}
+#define nan_to_num_v sphx_nan_to_num
 struct DevIntegArgs {
     int n;
     double *pos, *vel, *acc, *E, *T;
@@ -231,14 +227,9 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
             return;
         }
         const double ct_min = -a.red2[1];
-        const double huge = __longlong_as_double(0x7F7F7F7F7F7F7F7Fll);                 // "no gas particle voted"
-        const double ctv = (ct_min >= huge) ? a.dt_0 / 10.0 : ct_min + 0.0001;         // nsc:783-786
-        if (a.fixed_dt > 0.0) {
-            dt = a.fixed_dt;
-        } else {
-            dt = a.first ? a.dt_0 / 10.0 : fmax(a.dt_0 / 5.0, fmin(a.dt_0 * 2.0, ctv));   // drv:223-226
-            if (ctv > a.max_age) dt = a.max_age / 100.0;                                // drv:228-229
-        }
+        // +inf = "no gas particle voted" (votes are at most DBL_MAX)                      nsc:783-786
+        const double ctv = sphx_ct_value(ct_min > DBL_MAX, ct_min, a.dt_0);
+        dt = (a.fixed_dt > 0.0) ? a.fixed_dt : sphx_dt_rule(ctv, a.first, a.dt_0, a.max_age);   // drv:223-229
         if (i == 0) *a.dt_out = dt;
     }
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
@@ -249,32 +240,26 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
         pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
         vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
     }
-    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double an = sqrt(vis[0] * vis[0] + vis[1] * vis[1] + vis[2] * vis[2]);
-    if (vn - an * dt < 0.0) {
+    double x[3], old[3], tot[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vis[c] = -v[c] / dt;
-    }
+    for (int c = 0; c < 3; ++c) { x[c] = a.pos[3 * (size_t)i + c]; old[c] = a.acc[3 * (size_t)i + c]; }
+    sphx_leapfrog_update(dt, x, v, vis, pa, nullptr, old, tot);                  // drv:475-486
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double tot = pa[c] + vis[c];
-        const double old = a.acc[3 * (size_t)i + c];
-        a.pos[3 * (size_t)i + c] = a.pos[3 * (size_t)i + c] + (tot * (dt * dt)) / 2.0 + v[c] * dt;
-        a.vel[3 * (size_t)i + c] = v[c] + (tot + old) / 2.0 * dt;
-        a.acc[3 * (size_t)i + c] = tot;
+        a.pos[3 * (size_t)i + c] = x[c];
+        a.vel[3 * (size_t)i + c] = v[c];
+        a.acc[3 * (size_t)i + c] = tot[c];
     }
-    const double E = nan_to_num_v(a.E[i]) + nan_to_num_v(a.vh[i] * dt);
+    double E = a.E[i], T;
+    sphx_energy_update(dt, a.vh[i], a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
     a.E[i] = E;
-    a.T[i] = nan_to_num_v(E * (a.mu[i] * a.m_h) / (a.gam[i] * a.m[i] * a.kB));
+    a.T[i] = T;
 }
 // drv:233-238 on (n,3) arrays
 __global__ __launch_bounds__(256) void dev_clamp_kernel(int n3, double lim, double* pos, double* vel) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n3) return;
-    double q = pos[e];
-    q = (q > lim) ? lim : q;
-    q = (q < -lim) ? -lim : q;
-    pos[e] = nan_to_num_v(q);
+    pos[e] = sphx_clamp_pos(pos[e], lim);
     vel[e] = nan_to_num_v(vel[e]);
 }
 

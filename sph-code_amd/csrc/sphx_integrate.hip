@@ -6,12 +6,8 @@
 #pragma clang fp contract(off)
 #include <float.h>
 
-__device__ __forceinline__ double nan_to_num(double v) {
-    if (v != v) return 0.0;
-    if (v > DBL_MAX) return DBL_MAX;
-    if (v < -DBL_MAX) return -DBL_MAX;
-    return v;
-}
+#include "sphx_leapfrog.h"
+#define nan_to_num sphx_nan_to_num
 
 // ---- drv:233-238: clamp |x| <= 1e11 AU, nan_to_num(x), nan_to_num(v) -----------------------
 __global__ __launch_bounds__(256) void clamp_kernel(int n, double lim, double* x, double* y, double* z,
@@ -22,10 +18,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(int n, double lim, double* x
     double* v[3] = {vx, vy, vz};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double q = p[c][i];
-        q = (q > lim) ? lim : q;
-        q = (q < -lim) ? -lim : q;
-        p[c][i] = nan_to_num(q);
+        p[c][i] = sphx_clamp_pos(p[c][i], lim);
         v[c][i] = nan_to_num(v[c][i]);
     }
 }
@@ -156,20 +149,25 @@ int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h) {
     return SPHX_OK;
 }
 
+__global__ void prime_ct_kernel(u64* ct_bits) { *ct_bits = SPHX_CT_NONE; }
+int sphx_prime_ct(sphx_ctx* ctx, u64* ct_bits) {
+    hipLaunchKernelGGL(prime_ct_kernel, dim3(1), dim3(1), 0, ctx->stream, ct_bits);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 // ---- drv:222-229: dt from the crossing time ------------------------------------------------
 __global__ void dt_kernel(u64* ct_bits, double* dt_out, int first, double fixed_dt, double dt_0,
                           double max_age) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double dt;
     const u64 b = *ct_bits;
-    *ct_bits = 0x7F7F7F7F7F7F7F7Full;          // "none yet" again: the next step's pass 2 needs no memset
+    *ct_bits = SPHX_CT_NONE;                   // "none yet" again: the next step's pass 2 needs no priming
     if (fixed_dt > 0.0) {
         dt = fixed_dt;
     } else {
-        double ct = (b == 0x7F7F7F7F7F7F7F7Full) ? dt_0 / 10.0                       // nsc:783-784
-                                                 : __longlong_as_double((long long)b) + 0.0001;  // nsc:786
-        dt = first ? dt_0 / 10.0 : fmax(dt_0 / 5.0, fmin(dt_0 * 2.0, ct));           // drv:223-226
-        if (ct > max_age) dt = max_age / 100.0;                                      // drv:228-229
+        const double ct = sphx_ct_value(b == SPHX_CT_NONE, __longlong_as_double((long long)b), dt_0);   // nsc:783-786
+        dt = sphx_dt_rule(ct, first, dt_0, max_age);                                 // drv:223-229
     }
     *dt_out = dt;
 }
@@ -194,6 +192,7 @@ struct IntegArgs {
     const double* G;                                   // loop-form mode: del_pressure (physical sign); nullptr otherwise
     const double* dt;
     double m_h, kB;
+    int no_old;                                        // drv:484-485: no previous acceleration of this shape
 };
 __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,27 +215,20 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
             vis[c] = dg + nan_to_num(a.drag_re[3 * (size_t)i + c]) + vis[c];
         }
     }
-    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double an = sqrt(vis[0] * vis[0] + vis[1] * vis[1] + vis[2] * vis[2]);
-    if (vn - an * dt < 0.0) {                                 // drv:475
+    double x[3] = {a.x[i], a.y[i], a.z[i]};
+    double vv[3] = {v[0], v[1], v[2]};
+    double gr[3], old[3], tot[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vis[c] = -v[c] / dt;
-    }
-    double* P[3] = {a.x, a.y, a.z};
-    double* V[3] = {a.vx, a.vy, a.vz};
-    double* A[3] = {a.ax, a.ay, a.az};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        // drv:477: grav_accel + pressure_accel + visc_accel, added left to right
-        const double tot = a.grav ? (a.grav[3 * (size_t)i + c] + pa[c]) + vis[c] : pa[c] + vis[c];
-        const double old = A[c][i];
-        P[c][i] = P[c][i] + (tot * (dt * dt)) / 2.0 + v[c] * dt;   // drv:481
-        V[c][i] = v[c] + (tot + old) / 2.0 * dt;              // drv:482-486
-        A[c][i] = tot;
-    }
-    const double E = nan_to_num(a.E[i]) + nan_to_num(a.vh[i] * dt);          // drv:490
+    for (int c = 0; c < 3; ++c) gr[c] = a.grav ? a.grav[3 * (size_t)i + c] : 0.0;
+    old[0] = a.ax[i]; old[1] = a.ay[i]; old[2] = a.az[i];
+    sphx_leapfrog_update(dt, x, vv, vis, pa, a.grav ? gr : nullptr, a.no_old ? nullptr : old, tot);   // drv:475-486
+    a.x[i] = x[0]; a.y[i] = x[1]; a.z[i] = x[2];
+    a.vx[i] = vv[0]; a.vy[i] = vv[1]; a.vz[i] = vv[2];
+    a.ax[i] = tot[0]; a.ay[i] = tot[1]; a.az[i] = tot[2];
+    double E = a.E[i], T;
+    sphx_energy_update(dt, a.vh[i], a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
     a.E[i] = E;
-    a.T[i] = nan_to_num(E * (a.mu[i] * a.m_h) / (a.gam[i] * a.m[i] * a.kB));  // drv:491
+    a.T[i] = T;
 }
 
 int sphx_integrate(sphx_ctx* ctx, int64_t n) {
@@ -257,8 +249,135 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n) {
     a.G = ctx->loop_forms ? ctx->G.as<double>() : nullptr;
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
+    a.no_old = 0;
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// ---- the driver's inline statements as array functions (host pointers) ------------------------
+__global__ __launch_bounds__(256) void dt_rule_kernel(int n, const double* ct, const int* first, double dt_0,
+                                                      double max_age, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sphx_dt_rule(ct[i], first[i], dt_0, max_age);
+}
+static int up_(sphx_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
+    SPHX_TRY(sphx_ensure(ctx, b, bytes));
+    HIPCHK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SPHX_OK;
+}
+#define NEEDP(p) do { if (!(p)) return sphx_set_err(ctx, SPHX_E_ARG, "%s: argument %s is NULL", __func__, #p); } while (0)
+
+extern "C" int sphx_dt_rule(sphx_ctx* ctx, int64_t n, const double* ct, const int32_t* first, double* dt) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDP(ct); NEEDP(first); NEEDP(dt);
+    if (n < 1) return SPHX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(up_(ctx, ctx->in_a, ct, (size_t)n * 8));
+    SPHX_TRY(up_(ctx, ctx->in_b, first, (size_t)n * 4));
+    SPHX_TRY(sphx_ensure(ctx, ctx->out_a, (size_t)n * 8));
+    hipLaunchKernelGGL(dt_rule_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       ctx->in_a.as<double>(), ctx->in_b.as<int>(), ctx->cst.dt_0, ctx->cst.max_age, ctx->out_a.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dt, ctx->out_a.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}
+
+__global__ __launch_bounds__(256) void clamp_aos_kernel(int n3, double lim, double* pos, double* vel) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n3) return;
+    pos[e] = sphx_clamp_pos(pos[e], lim);
+    vel[e] = nan_to_num(vel[e]);
+}
+extern "C" int sphx_clamp_arrays(sphx_ctx* ctx, int64_t n, double* points, double* velocities) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDP(points); NEEDP(velocities);
+    if (n < 1) return SPHX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb3 = (size_t)n * 24;
+    SPHX_TRY(up_(ctx, ctx->in_a, points, nb3));
+    SPHX_TRY(up_(ctx, ctx->in_b, velocities, nb3));
+    hipLaunchKernelGGL(clamp_aos_kernel, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, ctx->stream, (int)(3 * n),
+                       ctx->cst.pos_clamp, ctx->in_a.as<double>(), ctx->in_b.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(points, ctx->in_a.p, nb3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(velocities, ctx->in_b.p, nb3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPHX_OK;
+}
+
+// drv:460-491 on host arrays: the SAME kernel the fused loop runs (integrate_kernel in loop-form
+// mode), fed from scratch buffers instead of the resident state.
+extern "C" int sphx_leapfrog(sphx_ctx* ctx, int64_t n, double* points, double* velocities, double* total_accel,
+                             const double* old_accel, double* E_internal, double* T, const double* mass,
+                             const double* mu, const double* gamma, const double* ptype, const double* grav_accel,
+                             const double* delp, const double* densities, const double* dust_densities,
+                             const double* drag_on_gas, const double* drag_reaction, const double* av_accel,
+                             const double* av_heat, double dt) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDP(points); NEEDP(velocities); NEEDP(total_accel); NEEDP(E_internal); NEEDP(T); NEEDP(mass); NEEDP(mu);
+    NEEDP(gamma); NEEDP(ptype); NEEDP(delp); NEEDP(densities); NEEDP(av_accel); NEEDP(av_heat);
+    if ((drag_on_gas != nullptr) != (drag_reaction != nullptr) || (drag_on_gas && !dust_densities))
+        return sphx_set_err(ctx, SPHX_E_ARG, "sphx_leapfrog: drag needs drag_on_gas, drag_reaction and dust_densities");
+    if (n < 1) return SPHX_OK;
+    if (n > 0x7FFFFFF0ll) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld out of range", (long long)n);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * 8;
+    // one scratch allocation: 9 SoA columns + E,T + 5 scalars + up to 7 (n,3)/(n,) inputs
+    DevBuf& w = ctx->out_b;
+    SPHX_TRY(sphx_ensure(ctx, w, 40 * nb));
+    double* base = w.as<double>();
+    size_t off = 0;
+    auto take = [&](size_t cols) { double* q = base + off; off += cols * (size_t)n; return q; };
+    double *x = take(1), *y = take(1), *z = take(1), *vx = take(1), *vy = take(1), *vz = take(1);
+    double *ax = take(1), *ay = take(1), *az = take(1), *E = take(1), *Tt = take(1);
+    double *m = take(1), *muu = take(1), *gm = take(1), *pt = take(1), *rho = take(1), *rhod = take(1), *heat = take(1);
+    double *aos = take(3), *G = take(3), *av = take(3), *gr = take(3), *don = take(3), *dre = take(3);
+    auto h2d = [&](double* d, const double* h, size_t cols) {
+        return hipMemcpyAsync(d, h, cols * nb, hipMemcpyHostToDevice, ctx->stream);
+    };
+    HIPCHK(h2d(aos, points, 3));
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, aos, x, y, z));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(h2d(aos, velocities, 3));
+    SPHX_TRY(sphx_aos_to_soa3(ctx, n, aos, vx, vy, vz));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (old_accel) {
+        HIPCHK(h2d(aos, old_accel, 3));
+        SPHX_TRY(sphx_aos_to_soa3(ctx, n, aos, ax, ay, az));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(h2d(E, E_internal, 1)); HIPCHK(h2d(m, mass, 1)); HIPCHK(h2d(muu, mu, 1)); HIPCHK(h2d(gm, gamma, 1));
+    HIPCHK(h2d(pt, ptype, 1)); HIPCHK(h2d(rho, densities, 1)); HIPCHK(h2d(heat, av_heat, 1));
+    HIPCHK(h2d(G, delp, 3)); HIPCHK(h2d(av, av_accel, 3));
+    if (dust_densities) HIPCHK(h2d(rhod, dust_densities, 1));
+    if (grav_accel) HIPCHK(h2d(gr, grav_accel, 3));
+    if (drag_on_gas) { HIPCHK(h2d(don, drag_on_gas, 3)); HIPCHK(h2d(dre, drag_reaction, 3)); }
+    double* dtd = ctx->scal.as<double>() + SC_NSLOTS - 1;          // a slot nothing else uses
+    HIPCHK(hipMemcpyAsync(dtd, &dt, 8, hipMemcpyHostToDevice, ctx->stream));
+    IntegArgs a;
+    a.n = (int)n;
+    a.x = x; a.y = y; a.z = z; a.vx = vx; a.vy = vy; a.vz = vz; a.ax = ax; a.ay = ay; a.az = az;
+    a.E = E; a.T = Tt; a.m = m; a.mu = muu; a.gam = gm; a.ptype = pt;
+    a.ha = nullptr; a.va = av; a.vh = heat; a.rho = rho; a.rhod = rhod;
+    a.drag_on = drag_on_gas ? don : nullptr; a.drag_re = drag_on_gas ? dre : nullptr;
+    a.grav = grav_accel ? gr : nullptr;
+    a.G = G;
+    a.dt = dtd;
+    a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
+    a.no_old = old_accel ? 0 : 1;
+    hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    struct Out { double* host; double *a, *b, *c; } outs[] = {{points, x, y, z}, {velocities, vx, vy, vz}, {total_accel, ax, ay, az}};
+    for (Out& o : outs) {
+        SPHX_TRY(sphx_soa3_to_aos_by_id(ctx, n, nullptr, o.a, o.b, o.c, aos));
+        HIPCHK(hipMemcpyAsync(o.host, aos, 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(E_internal, E, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(T, Tt, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }
 

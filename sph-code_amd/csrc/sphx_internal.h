@@ -208,6 +208,11 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 #define LAG_OFF 1024                 // byte offset of the lag slots in ctx->pinned: slot s at LAG_OFF + 512 s (box), + 256 (h sums)
 #endif
 
+// "no gas particle has voted a crossing time yet": the bits of +inf.  Votes are nan_to_num'ed
+// (at most DBL_MAX = 0x7FEF...), so no vote can produce it and atomicMin on the bits keeps any vote.
+#define SPHX_CT_NONE 0x7FF0000000000000ull
+int sphx_prime_ct(sphx_ctx* ctx, u64* ct_bits);      // writes SPHX_CT_NONE on the context's stream
+
 // scalar slots in ctx->scal (8-byte units)
 enum {
     SC_CT_BITS = 0,   // u64: min crossing time (bits of a positive double)

@@ -333,12 +333,12 @@ extern "C" int sphx_crossing_time(sphx_ctx* ctx, int64_t n, int k, const int64_t
     SPHX_TRY(loop_begin(ctx, n, k, neighbor, &a));
     UPF(in_b, velocities, 3 * n, vel); UPF(in_d, sizes, n, h); UPF(in_h, particle_type, n, pt);
     a.ct_bits = ctx->scal.as<u64>() + SC_CT_BITS;
-    HIPCHK(hipMemsetAsync(a.ct_bits, 0x7F, sizeof(u64), ctx->stream));
+    SPHX_TRY(sphx_prime_ct(ctx, a.ct_bits));
     ctx->ct_primed = false;
     LAUNCH1(loop_ct_kernel);
     u64 bits = 0;
     SPHX_TRY(down(ctx, &bits, a.ct_bits, sizeof(u64)));
-    if (bits == 0x7F7F7F7F7F7F7F7Full) {
+    if (bits == SPHX_CT_NONE) {
         *out = ctx->cst.dt_0 / 10.0;                      // nsc:783-784
     } else {
         double v;
@@ -773,8 +773,8 @@ int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
     hipLaunchKernelGGL(loop_prep_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
     const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
-    // 0x7F7F.. = huge finite "none yet"; the previous step's dt_kernel left it so
-    if (!ctx->ct_primed) HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));
+    // SPHX_CT_NONE = "none yet"; the previous step's dt_kernel left it so
+    if (!ctx->ct_primed) SPHX_TRY(sphx_prime_ct(ctx, ct));
     ctx->ct_primed = false;
     const int npad = (int)sphx_pad64(n);
     if (ctx->qorder && ctx->blob_lists) {

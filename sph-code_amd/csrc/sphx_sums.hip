@@ -316,8 +316,8 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
     SPHX_TRY(sphx_ensure(ctx, ctx->Pi, (size_t)n * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->Bw, (size_t)n * sizeof(double)));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
-    // 0x7F7F.. = huge finite "none yet"; in the fused loop the previous step's dt_kernel left it so
-    if (!ctx->ct_primed) HIPCHK(hipMemsetAsync(ct, 0x7F, sizeof(u64), ctx->stream));
+    // SPHX_CT_NONE = "none yet"; in the fused loop the previous step's dt_kernel left it so
+    if (!ctx->ct_primed) SPHX_TRY(sphx_prime_ct(ctx, ct));
     ctx->ct_primed = false;
     if (ctx->qorder && ctx->blob_lists) return sphx_blob_pi(ctx, n, k, ct);
     hipLaunchKernelGGL(pass_pi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -39,7 +39,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HUGE_CT = float(np.frombuffer(np.array([0x7F7F7F7F7F7F7F7F], dtype=np.uint64).tobytes(), dtype=np.float64)[0])
+HUGE_CT = float("inf")      # "no gas particle voted a crossing time" (SPHX_CT_NONE: votes are at most DBL_MAX)
 
 
 # ==============================================================================================
@@ -574,14 +574,14 @@ class DistributedSim:
             with self._sec("replan"):
                 self._replan()
             D = 0.0
-        elif self.force_replan > 0:
-            self.force_replan -= 1
+        elif self.force_replan > 0 or self.pos_plan is None:
+            # forced, or the last plan kept no positions to measure the displacement against: a plan
+            # made now is exact (D = 0); never compare against positions the plan was not made at
+            self.force_replan = max(self.force_replan - 1, 0)
             with self._sec("replan"):
                 self._replan()
             D = 0.0
         else:
-            if self.pos_plan is None:              # (the last plan was a forced one: nothing to compare with)
-                self.pos_plan = s["pos"].clone()
             with self._sec("stale_check"):
                 if no:
                     d_loc = float((s["pos"] - self.pos_plan).abs().max()) * 1.7320508075688772
