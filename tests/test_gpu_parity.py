@@ -758,3 +758,24 @@ def test_gpu_device_integrate_vs_driver_block():
     assert np.array_equal(pos.cpu().numpy(), o("points")) and np.array_equal(vel.cpu().numpy(), o("velocities"))
     assert np.array_equal(E.cpu().numpy(), o("E_internal")) and np.array_equal(T.cpu().numpy(), o("T"))
     ctx.close()
+
+
+def test_cloud_at_rest_takes_the_max_age_step(nsc):
+    """The reference's own initial condition has every velocity zero (drv:137): every gas particle's crossing
+    time is h/0 = inf -> DBL_MAX through nan_to_num (nsc:781-786), ct > MAX_AGE, so a step that is not the first
+    takes dt = MAX_AGE/100 (drv:228-229).  Array API, fused step (both step modes)."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K = 3000, 40
+    s = ics.uniform_cube(n)
+    s["velocities"] = np.zeros((n, 3))
+    idx, _, _, _, h = nsc.neighbors(s["points"], np.inf, K)
+    ct_ref = orc.crossing_time(idx, s["velocities"], h, s["particle_type"])
+    assert ct_ref > 1e307 and orc.timestep(ct_ref, False) == orc.MAX_AGE / 100.
+    assert nsc.crossing_time(idx, s["velocities"], h, s["particle_type"]) == ct_ref
+    for kw in (dict(), dict(forms="loop", d=1.25e6 * orc.AU)):
+        sim = Simulation(s, n_neigh=K, **kw)
+        sim.first = False
+        sim.step(1)
+        assert sim.download()["dt"] == orc.MAX_AGE / 100., kw
