@@ -72,6 +72,7 @@ typedef struct sphx_stats {
     int64_t rebuild_steps; /* steps with cell sort + full search                 */
     double  cell_size;     /* edge of the last grid's cells                     */
     double  ms_gravity;    /* self-gravity (0 unless sphx_state_set_gravity)    */
+    int64_t fallback_queries; /* last step: queries the grouped search left to the general kernel */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */

@@ -22,7 +22,7 @@ class SphxStats(C.Structure):
                                           "ms_visc", "ms_integrate", "ms_total")] + \
                [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
                                          "rebuild_steps")] + \
-               [("cell_size", C.c_double), ("ms_gravity", C.c_double)]
+               [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -83,6 +83,8 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
     if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
+    if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
     if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
     if (const char* e = getenv("SPHX_GRAV_ORDER")) { int v = atoi(e); if (v == 1 || v == 2) ctx->grav_order = v; }
@@ -143,7 +145,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
-                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp};
+                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -502,8 +504,11 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             o.dref = ctx->dref.as<double>();
             rs = ctx->rscale_build;          // wider: the list must hold 64 entries to earn its margin
         }
-        SPHX_TRY(sphx_knn(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), r.id.as<int>(),
-                          ctx->inv.as<int>(), r.hprev.as<double>(), rs, dist, o));
+        ctx->knn_hinted = ctx->step_count > 0 && !ctx->use_verlet;     // hprev holds the previous step's radii
+        const int rc_knn = sphx_knn(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), r.id.as<int>(),
+                                    ctx->inv.as<int>(), r.hprev.as<double>(), rs, dist, o);
+        ctx->knn_hinted = false;
+        SPHX_TRY(rc_knn);
         if (ctx->use_verlet) {
             SPHX_TRY(sphx_save_list_positions(ctx, n, r.x.as<double>(), r.y.as<double>(), r.z.as<double>()));
             ctx->list_valid = true;
@@ -634,6 +639,10 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->dt_last = ((const double*)ctx->pinned)[SC_DT];
     ctx->stats.candidates = (int64_t)sc[SC_CAND];
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
+    ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
+    if (getenv("SPHX_KG_DEBUG"))
+        fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu\n",
+                sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6]);
     return SPHX_OK;
 }
 

@@ -109,10 +109,12 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     o.h_sorted = nullptr; o.idx64 = nullptr; o.dist = nullptr; o.nontriv = nullptr;
     o.h_by_id = h_out;
     ctx->knn_hint_by_id = (hint != nullptr);
+    ctx->knn_hinted = (hint != nullptr);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     int rc = sphx_knn(ctx, n, k, xs, ys, zs, ctx->perm.as<int>(), ctx->inv.as<int>(), hint,
                       rscale > 0.0 ? rscale : ctx->rscale, dist, o);
     ctx->knn_hint_by_id = false;
+    ctx->knn_hinted = false;
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->dev_ev_pending = (rc == SPHX_OK);
     if (rc == SPHX_OK && ctx->qorder && ctx->use_lds) rc = sphx_blob_translate(ctx, n, k);

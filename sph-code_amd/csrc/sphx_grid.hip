@@ -361,11 +361,43 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     return SPHX_OK;
 }
 
-// ---- blob order: particles listed cell by cell along a Morton curve ---------------------------
-// Bits of (cx, cy, cz) interleaved from the least significant end, each axis contributing only the
-// bits it has, so the code space is at most 8x the cell count whatever the grid's aspect ratio.
-struct BlobBits { int bx, by, bz; };
+// ---- blob order: particles listed cell by cell along a space-filling curve -----------------------
+// Hilbert curve over the cube of side 2^b that holds the grid (b = bits of the longest axis) when its
+// code space fits (3b <= 27 bits): consecutive cells are face neighbours, so a run of consecutive
+// particles - a workgroup's blob, a wave's query group (sphx_knn_group.hip) - is one connected lump:
+// the box of 64 consecutive particles plus their search radius holds ~1300 candidates against ~2000 for
+// the Morton runs of the first version, which jump at every octant boundary (measured on the 1e6
+// polytrope).  Otherwise (a very elongated or very fine grid): Morton code with the bits of (cx, cy, cz)
+// interleaved from the least significant end, each axis contributing only the bits it has, so the code
+// space is at most 8x the cell count whatever the grid's aspect ratio.
+struct BlobBits { int bx, by, bz; int hilbert; };
+__device__ __forceinline__ unsigned hilbert_rank(unsigned x, unsigned y, unsigned z, int b) {
+    // Skilling's transform (axes -> transposed Hilbert index), then the transposed bits interleaved
+    unsigned X[3] = {x, y, z};
+    const unsigned M = 1u << (b - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    unsigned out = 0;
+    for (int q = 0; q < b; ++q) {
+        out |= ((X[2] >> q) & 1u) << (3 * q);
+        out |= ((X[1] >> q) & 1u) << (3 * q + 1);
+        out |= ((X[0] >> q) & 1u) << (3 * q + 2);
+    }
+    return out;
+}
 __device__ __forceinline__ unsigned blob_rank(int cx, int cy, int cz, BlobBits b) {
+    if (b.hilbert) return hilbert_rank((unsigned)cx, (unsigned)cy, (unsigned)cz, b.hilbert);
     unsigned out = 0;
     int pos = 0;
     for (int q = 0; q < 11; ++q) {
@@ -397,11 +429,17 @@ __global__ __launch_bounds__(256) void blob_scatter(int n, GridParams g, BlobBit
 // (left nullptr = identity when the code space would be unreasonably large).
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
     const GridParams g = ctx->grid;
-    BlobBits b{0, 0, 0};
+    BlobBits b{0, 0, 0, 0};
     while ((1 << b.bx) < g.nx) ++b.bx;
     while ((1 << b.by) < g.ny) ++b.by;
     while ((1 << b.bz) < g.nz) ++b.bz;
-    const int bits = b.bx + b.by + b.bz;
+    int bits = b.bx + b.by + b.bz;
+    int hb = b.bx > b.by ? b.bx : b.by;
+    if (b.bz > hb) hb = b.bz;
+    if (hb < 1) hb = 1;
+    // the cube's code space may be up to 8x the Morton one: taken while it stays within 2^24 codes (a
+    // 64 MB count + scan) or within 4x the tight code space
+    if (ctx->blob_curve != 1 && 3 * hb <= 27 && (3 * hb <= 24 || 3 * hb <= bits + 2)) { b.hilbert = hb; bits = 3 * hb; }
     ctx->qorder = nullptr;
     if (bits > 27) return SPHX_OK;
     const int M = 1 << bits;

@@ -354,7 +354,7 @@ extern "C" int sphx_leapfrog(sphx_ctx* ctx, int64_t n, double* points, double* v
     if (dust_densities) HIPCHK(h2d(rhod, dust_densities, 1));
     if (grav_accel) HIPCHK(h2d(gr, grav_accel, 3));
     if (drag_on_gas) { HIPCHK(h2d(don, drag_on_gas, 3)); HIPCHK(h2d(dre, drag_reaction, 3)); }
-    double* dtd = ctx->scal.as<double>() + SC_NSLOTS - 1;          // a slot nothing else uses
+    double* dtd = ctx->scal.as<double>() + 15;          // a slot nothing else uses
     HIPCHK(hipMemcpyAsync(dtd, &dt, 8, hipMemcpyHostToDevice, ctx->stream));
     IntegArgs a;
     a.n = (int)n;

@@ -118,6 +118,10 @@ struct sphx_ctx {
     const int* qorder = nullptr;    // nullptr: identity
     DevBuf porder, mcount, mstart;
     bool use_blob = true;
+    bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
+    bool knn_hinted = false;        // set by the callers of sphx_knn whose rsearch holds real previous radii
+    DevBuf fail_list;               // queries the grouped kernel hands to the general one (+ their count)
+    int blob_curve = 0;             // 0: Hilbert where its code space fits, 1: Morton always (SPHX_BLOB_CURVE)
     // sphx_blob.hip: per-workgroup distinct-neighbour lists + 16-bit slot lists for the LDS passes
     DevBuf slot16, uniq;
     bool use_lds = true;            // run the step loop's passes out of LDS (needs blob order)
@@ -224,7 +228,9 @@ enum {
     SC_NFAIL = 6,     // u64: particles whose refreshed kNN could not be proven exact
     SC_HCNT = 7,      // f64: number of h values in SC_HSUM
     SC_GRAV_EPS = 8,  // f64: gravitational softening = median(h) of this step (nsc:358)
-    SC_NSLOTS = 16
+    SC_NFAILQ = 9,    // u32: queries of the last hinted search left to the general kernel
+    SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
+    SC_NSLOTS = 24
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------

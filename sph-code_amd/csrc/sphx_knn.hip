@@ -44,9 +44,14 @@ struct KnnArgs {
     long long* nontriv;
     double* h_by_id;
     u64* counters;
+    // list mode (LIST = 1): the queries are the processing slots qlist[0 .. *qcount) - the ones the grouped
+    // search (sphx_knn_group.hip) could not certify; the grid is fixed and walks the list
+    const int* qlist;
+    const int* qcount;
 };
 
 #include "sphx_wave.h"
+#include "sphx_knn_group.h"
 
 // Sort the `cnt` staged entries at ring position `head` ascending by (key, index) into (ck, cv);
 // lanes >= cnt get the (INF, ~0) padding.  r2 = trial radius^2 bounds every staged key.
@@ -113,7 +118,7 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
 // LEAN = 1: the step loop's variant - only the K-major list and h (sorted order) are produced,
 // so the API / Verlet-list pointers are never loaded (17 pointers in SGPRs otherwise: measured
 // 20 % slower).  LEAN = 2: the same for the device API (h written by id).
-template <int ABL, int LEAN = 0>
+template <int ABL, int LEAN = 0, int LIST = 0>
 __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     extern __shared__ int tile_dyn[];                 // [K][KNN_PPB + 1] result tile (sized at launch)
 #define tile(kk, li) tile_dyn[(kk) * (KNN_PPB + 1) + (li)]
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int base = xcd_block(blockIdx.x, gridDim.x) * KNN_PPB;
+    const int total = LIST ? *a.qcount : a.n;          // queries: list entries, or all particles
+    int vblock = LIST ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x);
     const GridParams g = a.g;
     const int K = a.k;
     const int KT = (!LEAN && a.list64) ? 64 : K;
@@ -136,6 +142,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     for (int q = lane; q < KNN_FLAG_CAP / 4; q += 64) reinterpret_cast<u32*>(rflag)[q] = 0u;
     u64 ncand = 0, nretry = 0;
 
+    do {
+    if (LIST && vblock * KNN_PPB >= total) break;
+    const int base = vblock * KNN_PPB;
     // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
     // particle l) and broadcast through SGPRs as each comes up
     double qx = 0.0, qy = 0.0, qz = 0.0, qr = 0.0;
@@ -143,8 +152,9 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     int qs = 0;                      // where the lane's query particle is stored
     {
         const int ip = base + wave * (KNN_PPB / 4) + (lane & 15);
-        if (lane < KNN_PPB / 4 && ip < a.n) {
-            qs = a.qorder ? a.qorder[ip] : ip;
+        if (lane < KNN_PPB / 4 && ip < total) {
+            const int slot = LIST ? a.qlist[ip] : ip;
+            qs = a.qorder ? a.qorder[slot] : slot;
             qx = a.x[qs]; qy = a.y[qs]; qz = a.z[qs];
             qid = a.id[qs];
             qr = a.rsearch ? a.rsearch[a.hint_by_id ? qid : qs] * a.rscale : 0.0;
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         const int li = wave * (KNN_PPB / 4) + t16;
         const int oid = __builtin_amdgcn_readlane(qid, t16);
         // wave-uniform: past the end, or a ghost (a candidate, never a query)
-        if (base + li >= a.n || oid >= a.n_active) {
+        if (base + li >= total || oid >= a.n_active) {
             if (lane < K) tile(lane, li) = -1;
             continue;
         }
@@ -403,11 +413,21 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     }
     if (LEAN || a.nbr) {
         __syncthreads();
-        for (int kk = wave; kk < K; kk += KNN_BLOCK / 64) {
-            int i = base + lane;
-            if (i < a.npad) a.nbr[(long long)kk * a.npad + i] = tile(kk, lane);
+        if (LIST) {
+            const int i = base + lane;
+            const int slot = i < total ? a.qlist[i] : -1;
+            for (int kk = wave; kk < K; kk += KNN_BLOCK / 64)
+                if (slot >= 0) a.nbr[(long long)kk * a.npad + slot] = tile(kk, lane);
+            __syncthreads();                           // the tile is reused by the next list chunk
+        } else {
+            for (int kk = wave; kk < K; kk += KNN_BLOCK / 64) {
+                int i = base + lane;
+                if (i < a.npad) a.nbr[(long long)kk * a.npad + i] = tile(kk, lane);
+            }
         }
     }
+    vblock += gridDim.x;
+    } while (LIST);
     if (lane == 0 && a.counters) {
         atomicAdd(&a.counters[SC_CAND], ncand);
         if (nretry) atomicAdd(&a.counters[SC_RETRY], nretry);
@@ -466,10 +486,33 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         fprintf(stderr, "[sphx] knn ablation %d: %.4f ms\n", mode, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+    a.qlist = nullptr; a.qcount = nullptr;
     const bool lean = a.nbr && a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv && !a.h_by_id &&
                       a.counters;
     const bool lean2 = a.nbr && a.h_by_id && !a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv &&
                        a.counters;
+    // Hinted searches of the step loop and of the device API: the lane-per-query grouped kernel first, then this
+    // kernel in list mode for whatever it could not certify (sphx_knn_group.hip).
+    if ((lean || lean2) && ctx->use_group && ctx->knn_hinted && rsearch && ctx->exp_knn < 0) {
+        SPHX_TRY(sphx_ensure(ctx, ctx->fail_list, ((size_t)a.npad + 64) * sizeof(int)));
+        int* flist = ctx->fail_list.as<int>();
+        int* fcount = flist + a.npad;
+        HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
+        KnnGroupArgs ga;
+        ga.n = a.n; ga.k = a.k; ga.npad = a.npad; ga.n_active = a.n_active;
+        ga.x = a.x; ga.y = a.y; ga.z = a.z; ga.id = a.id; ga.qorder = a.qorder; ga.cell_start = a.cell_start;
+        ga.g = a.g; ga.rsearch = a.rsearch; ga.hint_by_id = a.hint_by_id; ga.rscale = a.rscale; ga.rbound = a.rbound;
+        ga.nbr = a.nbr; ga.h_sorted = lean ? a.h_sorted : nullptr; ga.h_by_id = lean2 ? a.h_by_id : nullptr;
+        ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
+        SPHX_TRY(sphx_knn_group(ctx, ga));
+        a.qlist = flist; a.qcount = fcount;
+        int lblocks = blocks < 1024 ? blocks : 1024;
+        if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
+        else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->scal.as<u64>() + SC_NFAILQ, fcount, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        return SPHX_OK;
+    }
     if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
     else if (lean2) hipLaunchKernelGGL((knn_kernel<0, 2>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
     else hipLaunchKernelGGL((knn_kernel<0, 0>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);

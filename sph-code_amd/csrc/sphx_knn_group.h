@@ -1,0 +1,30 @@
+// sphx_knn_group.h - arguments of the lane-per-query grouped search (sphx_knn_group.hip)
+#pragma once
+#include "sphx_internal.h"
+
+#ifndef KG_TCAP
+#define KG_TCAP 2048                     // candidates per group tile (11 bits of a key name the slot)
+#endif
+#define KG_MAXROWS 4096                  // rows of cells a group's tile may span
+static_assert(KG_TCAP <= 2048 && KG_TCAP % 64 == 0, "tile slots are named by 11 key bits");
+
+struct KnnGroupArgs {
+    int n, k, npad;
+    int n_active;              // queries with id >= n_active (ghosts) are skipped
+    const double *x, *y, *z;   // cell-sorted positions
+    const int* id;
+    const int* qorder;         // processing order (nullable: identity)
+    const int* cell_start;
+    GridParams g;
+    const double* rsearch;     // previous h: sorted order, or by id (hint_by_id)
+    int hint_by_id;
+    double rscale, rbound;
+    int* nbr;                  // [k][npad]
+    double* h_sorted;          // one of the two
+    double* h_by_id;
+    int* fail_list;            // processing slots this kernel could not certify
+    int* fail_count;
+    u64* counters;
+    u64* prof;                 // diagnostics (nullptr in the product): per-section cycle sums
+};
+int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a);
