@@ -143,16 +143,19 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     u64 ncand = 0, nretry = 0;
 
     do {
-    if (LIST && vblock * KNN_PPB >= total) break;
-    const int base = vblock * KNN_PPB;
+    // list mode: 4 queries per wave and pass instead of 16 - the list is short (a few per cent of the queries), so
+    // the launch is bound by how long one wave takes, not by how many waves there are
+    constexpr int PPB = LIST ? 16 : KNN_PPB;
+    if (LIST && vblock * PPB >= total) break;
+    const int base = vblock * PPB;
     // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
     // particle l) and broadcast through SGPRs as each comes up
     double qx = 0.0, qy = 0.0, qz = 0.0, qr = 0.0;
     int qid = 0x7FFFFFFF;
     int qs = 0;                      // where the lane's query particle is stored
     {
-        const int ip = base + wave * (KNN_PPB / 4) + (lane & 15);
-        if (lane < KNN_PPB / 4 && ip < total) {
+        const int ip = base + wave * (PPB / 4) + (lane & 15);
+        if (lane < PPB / 4 && ip < total) {
             const int slot = LIST ? a.qlist[ip] : ip;
             qs = a.qorder ? a.qorder[slot] : slot;
             qx = a.x[qs]; qy = a.y[qs]; qz = a.z[qs];
@@ -161,8 +164,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         }
     }
 
-    for (int t16 = 0; t16 < KNN_PPB / 4; ++t16) {
-        const int li = wave * (KNN_PPB / 4) + t16;
+    for (int t16 = 0; t16 < PPB / 4; ++t16) {
+        const int li = wave * (PPB / 4) + t16;
         const int oid = __builtin_amdgcn_readlane(qid, t16);
         // wave-uniform: past the end, or a ghost (a candidate, never a query)
         if (base + li >= total || oid >= a.n_active) {
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         __syncthreads();
         if (LIST) {
             const int i = base + lane;
-            const int slot = i < total ? a.qlist[i] : -1;
+            const int slot = (lane < PPB && i < total) ? a.qlist[i] : -1;
             for (int kk = wave; kk < K; kk += KNN_BLOCK / 64)
                 if (slot >= 0) a.nbr[(long long)kk * a.npad + slot] = tile(kk, lane);
             __syncthreads();                           // the tile is reused by the next list chunk
@@ -506,7 +509,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
         SPHX_TRY(sphx_knn_group(ctx, ga));
         a.qlist = flist; a.qcount = fcount;
-        int lblocks = blocks < 1024 ? blocks : 1024;
+        int lblocks = blocks < 2048 ? blocks : 2048;
         if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
         else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
         HIPCHK(hipGetLastError());

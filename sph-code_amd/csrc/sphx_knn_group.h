@@ -3,9 +3,9 @@
 #include "sphx_internal.h"
 
 #ifndef KG_TCAP
-#define KG_TCAP 2048                     // candidates per group tile (11 bits of a key name the slot)
+#define KG_TCAP 1920                     // candidates per group tile (11 bits of a key name the slot)
 #endif
-#define KG_MAXROWS 4096                  // rows of cells a group's tile may span
+#define KG_MAXROWS 512                   // rows of cells a group's tile may span (two per thread)
 static_assert(KG_TCAP <= 2048 && KG_TCAP % 64 == 0, "tile slots are named by 11 key bits");
 
 struct KnnGroupArgs {
