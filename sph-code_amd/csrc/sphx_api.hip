@@ -85,6 +85,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
     if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
     if (const char* e = getenv("SPHX_GRAV_ORDER")) { int v = atoi(e); if (v == 1 || v == 2) ctx->grav_order = v; }
@@ -442,8 +443,14 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     ctx->blob_lists = false;
     ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
     HIPCHK(hipEventRecord(ev[0], ctx->stream));
-    // drv:233-238
-    SPHX_TRY(sphx_clamp(ctx, n, ctx->st));
+    // drv:233-238: applied by the grid build's first pass over the particles (sphx_grid.hip); the Verlet path looks at
+    // the positions before any grid is built, so it clamps here
+    ctx->clamp_vx = nullptr;
+    if (ctx->use_verlet) {
+        SPHX_TRY(sphx_clamp(ctx, n, ctx->st));
+    } else {
+        ctx->clamp_vx = ctx->st.vx.as<double>(); ctx->clamp_vy = ctx->st.vy.as<double>(); ctx->clamp_vz = ctx->st.vz.as<double>();
+    }
     SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * ctx->npad * sizeof(int)));
     // ---- incremental exact kNN from the Verlet lists (sphx_refresh.hip) ---------------------
     bool searched = false;
@@ -483,13 +490,19 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         }
         {
             StateArrays& r = ctx->st;       // the box statistics are the previous step's when there are any
+            const bool blob = ctx->use_blob && !ctx->use_verlet;
             ctx->lag_on = true;
+            ctx->defer_cell_sort = blob;      // the blob-order pass over the cells sorts their members too
             const int rc_ = sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint);
             ctx->lag_on = false;
+            ctx->defer_cell_sort = false;
+            ctx->clamp_vx = nullptr;
             SPHX_TRY(rc_);
+            // (the blob order needs cell_of / perm / cell_start only: before the state is permuted, so that the
+            //  deferred member sort has run when perm is used)
+            if (blob) SPHX_TRY(sphx_build_blob_order(ctx, n));
         }
         SPHX_TRY(sphx_permute_state(ctx, n));
-        if (ctx->use_blob && !ctx->use_verlet) SPHX_TRY(sphx_build_blob_order(ctx, n));
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         StateArrays& r = ctx->st;
         KnnOut o;

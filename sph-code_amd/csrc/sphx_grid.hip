@@ -5,9 +5,12 @@
 // Coordinates outside the box are clamped into the boundary cells by the same monotone map
 // the search uses for its range ends, so clamping never loses a neighbour.
 #include "sphx_internal.h"
+#include <rocprim/rocprim.hpp>
+#include <float.h>
 
 #define RED_BLOCK 256
 #define RED_MAXBLOCKS 1024
+#define FUSED_MAXBLOCKS 4096        // grid_count_fused: one particle per thread up to 1e6 (histogram atomics want threads in flight)
 
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
@@ -74,16 +77,22 @@ __global__ __launch_bounds__(RED_BLOCK) void bbox_partial(int n, const double* x
         partial[blockIdx.x * BB_W + c] = v;
     }
 }
-// one wave per component: block c reduces partial[:, c]
-__global__ __launch_bounds__(64) void bbox_final(int nblocks, const double* partial, double* out) {
+// one block per component: block c reduces partial[:, c] (four waves, then their four results in a fixed order)
+__global__ __launch_bounds__(256) void bbox_final(int nblocks, const double* partial, double* out) {
+    __shared__ double sw[4];
     const int c = blockIdx.x;
     double v = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0);
-    for (int b = threadIdx.x; b < nblocks; b += 64) {
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
         const double p = partial[b * BB_W + c];
         v = c < 3 ? fmin(v, p) : (c < 6 ? fmax(v, p) : v + p);
     }
     v = c < 3 ? wave_min(v) : (c < 6 ? wave_max(v) : wave_sum(v));
-    if (threadIdx.x == 0) out[c] = v;
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a0 = sw[0], a1 = sw[1], a2 = sw[2], a3 = sw[3];
+        out[c] = c < 3 ? fmin(fmin(a0, a1), fmin(a2, a3)) : (c < 6 ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3));
+    }
 }
 
 // out_minmax[0..5] = bounding box of all finite points; [6..8] mean, [9..11] standard deviation,
@@ -96,11 +105,11 @@ static int bbox_launch(sphx_ctx* ctx, int64_t n, const double* x, const double* 
     for (int c = 0; c < 3; ++c) { clip.lo[c] = ctx->clip_lo[c]; clip.hi[c] = ctx->clip_hi[c]; }
     int blocks = (int)((n + RED_BLOCK - 1) / RED_BLOCK);
     if (blocks > RED_MAXBLOCKS) blocks = RED_MAXBLOCKS;
-    SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 1) * BB_W * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 2 + FUSED_MAXBLOCKS) * BB_W * sizeof(double)));
     double* part = ctx->bbox_tmp.as<double>();
     double* fin = part + (size_t)RED_MAXBLOCKS * BB_W;
     hipLaunchKernelGGL(bbox_partial, dim3(blocks), dim3(RED_BLOCK), 0, ctx->stream, (int)n, x, y, z, clip, part);
-    hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(64), 0, ctx->stream, blocks, part, fin);
+    hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(256), 0, ctx->stream, blocks, part, fin);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_dst, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return SPHX_OK;
@@ -142,6 +151,101 @@ __global__ __launch_bounds__(256) void cell_count(int n, const double* x, const 
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_of[i] = c;
     atomicAdd(&hist[c], 1);
+}
+
+// ---- the fused loop's first pass over the particles: drv:233-238 clamp (optional) + bounding-box statistics +
+// cell ids and histogram in ONE kernel (was: clamp_kernel, bbox_partial, bbox_final, cell_count).  Possible
+// because the fused loop sizes its grid from the PREVIOUS step's statistics: g is known before this step's
+// positions have been looked at.  bbox_final then reduces the block partials as before (a last-block-done ticket
+// inside this kernel was tried: its release fence writes back every dirty line the histogram atomics and the
+// clamped positions left in the L2 - 441 us instead of 60).
+struct FusedCountArgs {
+    int n;
+    double *x, *y, *z, *vx, *vy, *vz;      // vx == nullptr: no clamp
+    double lim;
+    ClipBox clip;
+    GridParams g;
+    int* cell_of;
+    int* hist;
+    double* partial;
+    unsigned* ticket;
+    double* fin;
+    u64* ct_reset;                          // "no crossing-time vote yet" for this step's pass 2 (nullable)
+};
+__device__ __forceinline__ double nan_to_num_g(double v) {
+    if (v != v) return 0.0;
+    if (v > DBL_MAX) return DBL_MAX;
+    if (v < -DBL_MAX) return -DBL_MAX;
+    return v;
+}
+__global__ __launch_bounds__(RED_BLOCK) void grid_count_fused(FusedCountArgs a) {
+    __shared__ double sm[RED_BLOCK / 64][BB_W];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double su[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
+    const GridParams g = a.g;
+    if (a.ct_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.ct_reset = SPHX_CT_NONE;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        double v[3] = {a.x[i], a.y[i], a.z[i]};
+        if (a.vx) {                                            // drv:233-238
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double q = v[c];
+                q = (q > a.lim) ? a.lim : q;
+                q = (q < -a.lim) ? -a.lim : q;
+                v[c] = nan_to_num_g(q);
+            }
+            a.x[i] = v[0]; a.y[i] = v[1]; a.z[i] = v[2];
+            a.vx[i] = nan_to_num_g(a.vx[i]); a.vy[i] = nan_to_num_g(a.vy[i]); a.vz[i] = nan_to_num_g(a.vz[i]);
+        }
+        if (isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2])) {
+            bool in = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                mn[c] = fmin(mn[c], v[c]); mx[c] = fmax(mx[c], v[c]);
+                if (a.clip.on && (v[c] < a.clip.lo[c] || v[c] > a.clip.hi[c])) in = false;
+            }
+            if (in) {
+                cnt += 1.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { su[c] += v[c]; sq[c] += v[c] * v[c]; }
+            }
+        }
+        const int cx = cell_coord_g(v[0], g.xmin, g.inv_cell, g.nx - 1);
+        const int cy = cell_coord_g(v[1], g.ymin, g.inv_cell, g.ny - 1);
+        const int cz = cell_coord_g(v[2], g.zmin, g.inv_cell, g.nz - 1);
+        const int c = (cz * g.ny + cy) * g.nx + cx;
+        a.cell_of[i] = c;
+        atomicAdd(&a.hist[c], 1);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mn[c] = wave_min(mn[c]); mx[c] = wave_max(mx[c]); su[c] = wave_sum(su[c]); sq[c] = wave_sum(sq[c]);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) {
+            sm[wave][c] = mn[c]; sm[wave][3 + c] = mx[c]; sm[wave][6 + c] = su[c]; sm[wave][9 + c] = sq[c];
+        }
+        sm[wave][12] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < BB_W) {
+        const int c = threadIdx.x;
+        double v = sm[0][c];
+        for (int w = 1; w < RED_BLOCK / 64; ++w)
+            v = c < 3 ? fmin(v, sm[w][c]) : (c < 6 ? fmax(v, sm[w][c]) : v + sm[w][c]);
+        a.partial[blockIdx.x * BB_W + c] = v;
+    }
+}
+
+// exclusive scan of n ints, out[n] = total (in[n] must be 0): rocPRIM's single-pass look-back scan
+static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+    SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, bytes + 64));
+    HIPCHK(rocprim::exclusive_scan(ctx->scan_tmp.p, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+    return SPHX_OK;
 }
 
 // three-phase exclusive scan of int32: 2048 items per block
@@ -246,6 +350,12 @@ __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* 
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint) {
     double bb[13];
+    // the statistics window of the robust box as the previous build left it (this build moves it)
+    ClipBox clip0;
+    clip0.on = ctx->clip_valid ? 1 : 0;
+    for (int c = 0; c < 3; ++c) { clip0.lo[c] = ctx->clip_lo[c]; clip0.hi[c] = ctx->clip_hi[c]; }
+    bool fused = false;           // this step's statistics come out of the cell-count kernel itself
+    int lag_cur = 0;
     if (ctx->lag_on) {
         // Fused step loop: this step's statistics are launched and copied out, the grid is sized from
         // the previous step's (already on the host) - the loop never waits for the step it launches.
@@ -254,22 +364,30 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         // the search reads, is this step's.)
         const int prev = ctx->lag_bslot, cur = prev ^ 1;
         char* slot = (char*)ctx->pinned + LAG_OFF;
-        SPHX_TRY(bbox_launch(ctx, n, x, y, z, true, slot + 512 * cur));
-        HIPCHK(hipEventRecord(ctx->lag_bev[cur], ctx->stream));
         // (the previous statistics describe this cloud if they were taken over about as many particles: the
         //  fused loop's n is constant, the decomposed driver's owned + ghost count wobbles by a few per cent)
         const int64_t pn = ctx->lag_bn[prev];
         const int use = (ctx->lag_bvalid[prev] && pn > 0 && (n > pn ? n - pn : pn - n) * 4 <= n) ? prev : cur;
+        lag_cur = cur;
+        fused = (use == prev) && ctx->fuse_count;
+        if (!fused) {
+            if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
+            SPHX_TRY(bbox_launch(ctx, n, x, y, z, true, slot + 512 * cur));
+            HIPCHK(hipEventRecord(ctx->lag_bev[cur], ctx->stream));
+        }
         HIPCHK(hipEventSynchronize(ctx->lag_bev[use]));
         bbox_finish(slot + 512 * use, bb);
         ctx->lag_bvalid[cur] = true;
         ctx->lag_bn[cur] = n;
         ctx->lag_bslot = cur;
     } else {
+        if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
         SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, true));
     }
-    if (ctx->clip_valid && bb[12] < 0.5 * (double)n)       // the clip box lost the cloud: re-anchor
+    if (ctx->clip_valid && bb[12] < 0.5 * (double)n) {     // the clip box lost the cloud: re-anchor
+        if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
         SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, false));
+    }
     double tmin[3], tmax[3];
     for (int c = 0; c < 3; ++c) {
         if (!(bb[3 + c] >= bb[c])) { bb[c] = 0.0; bb[3 + c] = 0.0; }   // no finite coordinate
@@ -348,15 +466,51 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         ctx->cell_fill_zeroed = ctx->cell_fill.p;
     }
     int pb = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
-                       ctx->cell_of.as<int>(), fill);
-    hipLaunchKernelGGL(scan_phase1, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum);
-    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, nblk, bsum, bsum + nblk);
-    hipLaunchKernelGGL(scan_phase3, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, nc, fill, bsum, start);
+    (void)bsum;
+    if (fused) {
+        // clamp (when the step asked for it) + this step's box statistics + cell ids + histogram: one pass
+        const bool fresh = ctx->bbox_tmp.p == nullptr;
+        SPHX_TRY(sphx_ensure(ctx, ctx->bbox_tmp, (size_t)(RED_MAXBLOCKS + 2 + FUSED_MAXBLOCKS) * BB_W * sizeof(double)));
+        double* fin = ctx->bbox_tmp.as<double>() + (size_t)RED_MAXBLOCKS * BB_W;     // (where bbox_final writes: ctx->tbox)
+        unsigned* ticket = reinterpret_cast<unsigned*>(fin + BB_W);
+        double* part = fin + 2 * BB_W;
+        if (fresh || !ctx->bbox_ticket_zeroed) {
+            HIPCHK(hipMemsetAsync(ticket, 0, sizeof(double), ctx->stream));
+            ctx->bbox_ticket_zeroed = true;
+        }
+        FusedCountArgs fa;
+        fa.n = (int)n;
+        fa.x = const_cast<double*>(x); fa.y = const_cast<double*>(y); fa.z = const_cast<double*>(z);
+        fa.vx = ctx->clamp_vx; fa.vy = ctx->clamp_vy; fa.vz = ctx->clamp_vz;
+        fa.lim = ctx->cst.pos_clamp;
+        fa.clip = clip0;
+        fa.g = g;
+        fa.cell_of = ctx->cell_of.as<int>();
+        fa.hist = fill;
+        fa.partial = part; fa.ticket = ticket; fa.fin = fin;
+        fa.ct_reset = nullptr;
+        int fb = pb < FUSED_MAXBLOCKS ? pb : FUSED_MAXBLOCKS;
+        hipLaunchKernelGGL(grid_count_fused, dim3(fb), dim3(RED_BLOCK), 0, ctx->stream, fa);
+        hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(256), 0, ctx->stream, fb, part, fin);
+        HIPCHK(hipGetLastError());
+        ctx->clamp_vx = nullptr;
+        char* slot = (char*)ctx->pinned + LAG_OFF;
+        HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->lag_bev[lag_cur], ctx->stream));
+    } else {
+        hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
+                           ctx->cell_of.as<int>(), fill);
+    }
+    SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc));
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>());
-    hipLaunchKernelGGL(cell_sort_members, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, nc, start,
-                       ctx->perm.as<int>());
+    ctx->cells_unsorted = false;
+    if (ctx->defer_cell_sort) {
+        ctx->cells_unsorted = true;          // sphx_build_blob_order's per-cell pass sorts the members too
+    } else {
+        hipLaunchKernelGGL(cell_sort_members, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, nc, start,
+                           ctx->perm.as<int>());
+    }
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -407,11 +561,22 @@ __device__ __forceinline__ unsigned blob_rank(int cx, int cy, int cz, BlobBits b
     }
     return out;
 }
-__global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount) {
+// one thread per cell; sort_perm != nullptr: also sorts the cell's members (cell_sort_members, deferred to here)
+__global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount,
+                                                  int* sort_perm) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.ncells) return;
-    const int cnt = cell_start[c + 1] - cell_start[c];
+    const int s0 = cell_start[c], e0 = cell_start[c + 1];
+    const int cnt = e0 - s0;
     if (cnt == 0) return;
+    if (sort_perm && cnt <= 512) {
+        for (int i = s0 + 1; i < e0; ++i) {
+            const int v = sort_perm[i];
+            int j = i - 1;
+            while (j >= s0 && sort_perm[j] > v) { sort_perm[j + 1] = sort_perm[j]; --j; }
+            sort_perm[j + 1] = v;
+        }
+    }
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     mcount[blob_rank(cx, cy, cz, b)] = cnt;
 }
@@ -441,22 +606,25 @@ int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
     // 64 MB count + scan) or within 4x the tight code space
     if (ctx->blob_curve != 1 && 3 * hb <= 27 && (3 * hb <= 24 || 3 * hb <= bits + 2)) { b.hilbert = hb; bits = 3 * hb; }
     ctx->qorder = nullptr;
-    if (bits > 27) return SPHX_OK;
+    if (bits > 27) {
+        if (ctx->cells_unsorted) {
+            hipLaunchKernelGGL(cell_sort_members, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, ctx->stream,
+                               g.ncells, ctx->cell_start.as<int>(), ctx->perm.as<int>());
+            ctx->cells_unsorted = false;
+        }
+        return SPHX_OK;
+    }
     const int M = 1 << bits;
     SPHX_TRY(sphx_ensure(ctx, ctx->porder, (size_t)n * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->mcount, ((size_t)M + 2) * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->mstart, ((size_t)M + 2) * sizeof(int)));
-    const int nblk = (M + SCAN_TILE - 1) / SCAN_TILE;
-    SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, ((size_t)nblk + 2) * sizeof(int)));
     int* mc = ctx->mcount.as<int>();
     int* ms = ctx->mstart.as<int>();
-    int* bsum = ctx->scan_tmp.as<int>();
     HIPCHK(hipMemsetAsync(mc, 0, ((size_t)M + 1) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(blob_count, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, ctx->stream, g, b,
-                       ctx->cell_start.as<int>(), mc);
-    hipLaunchKernelGGL(scan_phase1, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, M, mc, bsum);
-    hipLaunchKernelGGL(scan_phase2, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, nblk, bsum, bsum + nblk);
-    hipLaunchKernelGGL(scan_phase3, dim3(nblk), dim3(SCAN_BLOCK), 0, ctx->stream, M, mc, bsum, ms);
+                       ctx->cell_start.as<int>(), mc, ctx->cells_unsorted ? ctx->perm.as<int>() : nullptr);
+    ctx->cells_unsorted = false;
+    SPHX_TRY(excl_scan_plus_total(ctx, mc, ms, M));
     hipLaunchKernelGGL(blob_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, b,
                        ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->cell_start.as<int>(), ms,
                        ctx->porder.as<int>());

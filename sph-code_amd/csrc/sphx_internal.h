@@ -118,6 +118,11 @@ struct sphx_ctx {
     const int* qorder = nullptr;    // nullptr: identity
     DevBuf porder, mcount, mstart;
     bool use_blob = true;
+    // the fused loop's first pass (sphx_grid.hip grid_count_fused): clamp + box statistics + cell histogram in one kernel
+    bool fuse_count = true;               // SPHX_FUSE_COUNT=0: the separate kernels
+    double *clamp_vx = nullptr, *clamp_vy = nullptr, *clamp_vz = nullptr;   // set by the step: the grid build applies drv:233-238
+    bool bbox_ticket_zeroed = false;
+    bool defer_cell_sort = false, cells_unsorted = false;   // the per-cell member sort rides in the blob-order pass
     bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
     bool knn_hinted = false;        // set by the callers of sphx_knn whose rsearch holds real previous radii
     DevBuf fail_list;               // queries the grouped kernel hands to the general one (+ their count)
