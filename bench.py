@@ -61,14 +61,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", dest="n", type=int, default=1_000_000, help="particles per GPU")
-    ap.add_argument("--workload", default="polytrope")
+    ap.add_argument("--workload", default=None,
+                    help="default: polytrope at 1 GPU (BASELINE configs[1]); uniform_cube in loop-form mode at N > 1 GPUs "
+                         "(configs[3]: the reference's own IC and its time loop's own sums, natural density)")
     ap.add_argument("--neigh", dest="k", type=int, default=40, help="N_NEIGH")
     ap.add_argument("--cpu-particles", dest="cpu_n", type=int, default=600_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dt", default="reference", choices=["reference", "cfl"],
                     help="time step: the reference's rule (drv:222-229; the BASELINE metric) or a fixed Courant-"
                          "limited step (ics.cfl_dt) under which the dense 1e6 workloads stay stable")
-    ap.add_argument("--forms", default="hydro_update", choices=["hydro_update", "loop"],
+    ap.add_argument("--forms", default=None, choices=["hydro_update", "loop"],
                     help="sums of the step: nsc.hydro_update's (the BASELINE metric) or the loop forms of the reference's "
                          "time loop (sphx_state_set_loop_forms; d set so that h(m) ~ the median kNN radius)")
     ap.add_argument("--clip-grad", action="store_true",
@@ -82,7 +84,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("SPHX_FORCE_DIST") == "1":     # the latter: 1-rank rehearsal of the RCCL path
+    if args.gpus > 1 and world == 1 and os.environ.get("SPHX_FORCE_DIST") != "1":
+        # one process per GPU: start the ranks as children (never re-exec a process that may have touched the GPU)
+        import subprocess
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    multi = world > 1 or os.environ.get("SPHX_FORCE_DIST") == "1"
+    if args.workload is None:
+        args.workload = "uniform_cube" if world > 1 else "polytrope"
+        if args.forms is None and world > 1:
+            args.forms = "loop"
+    if args.forms is None:
+        args.forms = "hydro_update"
+    if multi:                                                     # (SPHX_FORCE_DIST=1: 1-rank rehearsal of the RCCL path)
         from sph_code_amd import multigpu
         return multigpu.bench_main(args, rank, local_rank, world)
 
@@ -96,12 +115,7 @@ def main():
     # 1 at the BASELINE size; see ics.bench_size_scale
     scale = (args.n / 1e6) ** (1. / 3.) if (args.natural_size and args.n > 1e6) else ics.bench_size_scale(args.n)
     state = ics.WORKLOADS[args.workload](args.n, size_scale=scale)
-    d_loop = None
-    if args.forms == "loop":
-        from scipy.spatial import cKDTree
-        sub = state["points"][:: max(1, args.n // 200000)]
-        hs = cKDTree(sub).query(sub, k=args.k)[0][:, -1] * (len(sub) / args.n) ** (1. / 3.)
-        d_loop = float(np.median(hs) / np.median((state["mass"] / 10 ** 1.5 / 1.989e30) ** (1. / 3.)))
+    d_loop = ics.loop_d(state, args.k) if args.forms == "loop" else None
     sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad,
                      forms=args.forms, d=d_loop)
     fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0

@@ -331,6 +331,25 @@ int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* pos, double*
                             const double* gamma, const double* ptype, const double* hydro_accel,
                             const double* visc_accel, const double* visc_heat, const double* red2,
                             int first, double fixed_dt, double* dt_out);
+/* ---- the same protocol on the LOOP FORMS of the reference's time loop (drv:451-458; multigpu.py, forms = "loop") ---- *
+ * after sphx_dev_search: gather the caller's owned + ghost arrays (n_total; E_internal too: del_pressure reads the
+ * neighbour's, nsc:755) and build the step's records; d = the driver's global d (drv:68).                               */
+int sphx_dev_loop_prep(sphx_ctx* ctx, const double* pos, const double* vel, const double* mass, const double* T,
+                       const double* mu, const double* gamma, const double* ptype, const double* E_internal, double d);
+/* nsc.density, dust_density, num_dens, del_pressure (nsc:693-717,744-774) for the owned particles; h_complete (n_total):
+ * owned from sphx_dev_search, ghosts from their owners (dust_density uses the neighbour's radius, nsc:711).
+ * Outputs caller order, (n_total,) / (n_total,3), owned entries written, any may be NULL.                              */
+int sphx_dev_loop_pass1(sphx_ctx* ctx, const double* h_complete, double* rho, double* rho_dust, double* nden, double* delp);
+/* nsc.artificial_viscosity + crossing_time (nsc:776-816); rho_complete (n_total): ghosts' from their owners (nsc:803).
+ * ct_out as sphx_dev_pi.                                                                                                */
+int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_accel, double* visc_heat, double* ct_out);
+/* drv:460-491 on those outputs: pressure_accel = delp / rho [gas], visc_accel = av[0].  red2 == NULL: the step `dt`;
+ * else verdict and dt on the device as sphx_dev_integrate_auto (dt_out required).                                       */
+int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                            double* E_internal, double* T, const double* mass, const double* mu, const double* gamma,
+                            const double* ptype, const double* delp, const double* rho, const double* av_accel,
+                            const double* av_heat, const double* red2, int first, double fixed_dt, double dt,
+                            double* dt_out);
 /* multigpu.py DistributedSim._replan: w_i = max((halo_scale + skin_frac) h_i, halo_scale h_i + |v_i| dt_last), the
  * reach an owned particle claims (h, w (n), vel (n,3): device).                                          */
 int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,

@@ -212,6 +212,7 @@ struct DevIntegArgs {
     int n;
     double *pos, *vel, *acc, *E, *T;
     const double *m, *mu, *gam, *ptype, *ha, *va, *vh;
+    const double *G, *rho;        // loop-form mode (G != nullptr): ha unused; pressure = G / rho [gas], visc = va (drv:460,473)
     double dt, m_h, kB, lim;
     // device-side verdict and dt (sphx_dev_integrate_auto): red2 = {halo too thin?, -min crossing time}
     const double* red2;
@@ -239,8 +240,13 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         v[c] = a.vel[3 * (size_t)i + c];
-        pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
-        vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
+        if (a.G) {                                            // the loop forms carry the physical sign themselves
+            pa[c] = nan_to_num_v(a.G[3 * (size_t)i + c] / a.rho[i] * g);     // drv:460
+            vis[c] = a.va[3 * (size_t)i + c];                                // av[0], drv:473
+        } else {
+            pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
+            vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
+        }
     }
     double x[3], old[3], tot[3];
 #pragma unroll
@@ -290,6 +296,7 @@ extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, d
     a.pos = pos; a.vel = vel; a.acc = accel_old; a.E = E_internal; a.T = T;
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
+    a.G = nullptr; a.rho = nullptr;
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
@@ -316,7 +323,35 @@ extern "C" int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* p
     a.pos = pos; a.vel = vel; a.acc = accel_old; a.E = E_internal; a.T = T;
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
+    a.G = nullptr; a.rho = nullptr;
     a.dt = 0.0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
+    a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
+    a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
+    hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// drv:460-491 on the loop forms' outputs (multigpu.py, forms = "loop"): pressure_accel = delp / rho [gas],
+// visc_accel = av[0]; red2 == NULL: dt as given; else verdict and dt on the device as sphx_dev_integrate_auto.
+extern "C" int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,
+                                       double* E_internal, double* T, const double* mass, const double* mu,
+                                       const double* gamma, const double* ptype, const double* delp, const double* rho,
+                                       const double* av_accel, const double* av_heat, const double* red2, int first,
+                                       double fixed_dt, double dt, double* dt_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(pos); NEED(vel); NEED(accel_old); NEED(E_internal); NEED(T); NEED(mass); NEED(mu); NEED(gamma);
+    NEED(ptype); NEED(delp); NEED(rho); NEED(av_accel); NEED(av_heat);
+    if (red2 && !dt_out) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_integrate_loop: red2 without dt_out");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n_owned < 1) return SPHX_OK;
+    DevIntegArgs a;
+    a.n = (int)n_owned;
+    a.pos = pos; a.vel = vel; a.acc = accel_old; a.E = E_internal; a.T = T;
+    a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
+    a.ha = nullptr; a.va = av_accel; a.vh = av_heat;
+    a.G = delp; a.rho = rho;
+    a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);

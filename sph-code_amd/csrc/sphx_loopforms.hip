@@ -752,16 +752,16 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop2_kernel(int n,
     }
 }
 
-int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
-    StateArrays& st = ctx->st;
+// The three launches of the loop-form sums on a set of SORTED state arrays `st` (the fused loop: the resident
+// state; the device-pointer API: a gathered copy of the caller's owned + ghost arrays).
+static int loop_prep_launch(sphx_ctx* ctx, int64_t n, double d, StateArrays& st) {
     const size_t nb = (size_t)n * sizeof(double);
-    DevBuf* outs1[] = {&ctx->rho, &ctx->rhod, &ctx->nden, &ctx->vh};
-    for (DevBuf* b : outs1) SPHX_TRY(sphx_ensure(ctx, *b, nb));
+    DevBuf* outs[] = {&ctx->rho, &ctx->rhod, &ctx->nden, &ctx->vh};
+    for (DevBuf* b : outs) SPHX_TRY(sphx_ensure(ctx, *b, nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->G, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->va, 3 * nb));
     SPHX_TRY(sphx_ensure(ctx, ctx->lrec_a, (size_t)n * sizeof(RecP1)));
     SPHX_TRY(sphx_ensure(ctx, ctx->lrec_v, (size_t)n * sizeof(RecP2)));
-    const unsigned grid = (unsigned)((n + 255) / 256);
     LoopPrepArgs p;
     p.n = (int)n;
     p.x = st.x.as<double>(); p.y = st.y.as<double>(); p.z = st.z.as<double>();
@@ -770,40 +770,189 @@ int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
     p.mu = st.mu.as<double>(); p.gam = st.gam.as<double>(); p.E = st.E.as<double>(); p.T = st.T.as<double>();
     p.d = d; p.m0 = ctx->cst.m_0; p.m_h = ctx->cst.m_h; p.kB = ctx->cst.k_B; p.amu = ctx->cst.amu;
     p.p1 = ctx->lrec_a.as<RecP1>(); p.p2 = ctx->lrec_v.as<RecP2>();
-    hipLaunchKernelGGL(loop_prep_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL(loop_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+static int loop_attr(sphx_ctx* ctx) {
+    if (!ctx->loop_attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop1_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
+        ctx->loop_attr_set = true;
+    }
+    return SPHX_OK;
+}
+// pass 1: h = the neighbours' kNN radii (dust_density, nsc:704-717), sorted order
+static int loop_pass1_launch(sphx_ctx* ctx, int64_t n, int k, double d, StateArrays& st, const double* h) {
     const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
+    const int npad = (int)sphx_pad64(n);
+    RecP1* p1 = ctx->lrec_a.as<RecP1>(); RecP2* p2 = ctx->lrec_v.as<RecP2>();
+    if (ctx->qorder && ctx->blob_lists) {
+        SPHX_TRY(loop_attr(ctx));
+        const int nblk = (npad + BLOB_P - 1) / BLOB_P;
+        const int g = sphx_blob_grid(ctx, nblk);
+        hipLaunchKernelGGL(blob_loop1_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
+                           d9, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p1,
+                           st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(), h,
+                           ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), p2);
+    } else {
+        hipLaunchKernelGGL(loop_pass1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, npad, k, d9,
+                           ctx->nbr.as<int>(), p1, st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(),
+                           h, ctx->qorder, ctx->rho.as<double>(), ctx->rhod.as<double>(),
+                           ctx->nden.as<double>(), ctx->G.as<double>(), p2);
+    }
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+// pass 2: h = each particle's OWN kNN radius (crossing time, nsc:782); an entry of 0 casts no vote
+static int loop_pass2_launch(sphx_ctx* ctx, int64_t n, int k, StateArrays& st, const double* h, u64* ct) {
+    const int npad = (int)sphx_pad64(n);
+    RecP1* p1 = ctx->lrec_a.as<RecP1>(); RecP2* p2 = ctx->lrec_v.as<RecP2>();
+    if (ctx->qorder && ctx->blob_lists) {
+        SPHX_TRY(loop_attr(ctx));
+        const int nblk = (npad + BLOB_P - 1) / BLOB_P;
+        const int g = sphx_blob_grid(ctx, nblk);
+        hipLaunchKernelGGL(blob_loop2_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
+                           ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p1, p2,
+                           st.m.as<double>(), h, ctx->va.as<double>(), ctx->vh.as<double>(), ct);
+    } else {
+        hipLaunchKernelGGL(loop_pass2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, npad, k,
+                           ctx->nbr.as<int>(), p1, p2, st.m.as<double>(), h, ctx->qorder, ctx->va.as<double>(),
+                           ctx->vh.as<double>(), ct);
+    }
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d) {
+    StateArrays& st = ctx->st;
+    SPHX_TRY(loop_prep_launch(ctx, n, d, st));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     // SPHX_CT_NONE = "none yet"; the previous step's dt_kernel left it so
     if (!ctx->ct_primed) SPHX_TRY(sphx_prime_ct(ctx, ct));
     ctx->ct_primed = false;
-    const int npad = (int)sphx_pad64(n);
-    if (ctx->qorder && ctx->blob_lists) {
-        if (!ctx->loop_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop1_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_loop2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
-            ctx->loop_attr_set = true;
-        }
-        const int nblk = (npad + BLOB_P - 1) / BLOB_P;
-        const int g = sphx_blob_grid(ctx, nblk);
-        hipLaunchKernelGGL(blob_loop1_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
-                           d9, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p.p1,
-                           st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(), st.hprev.as<double>(),
-                           ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(),
-                           p.p2);
-        hipLaunchKernelGGL(blob_loop2_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
-                           ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p.p1, p.p2,
-                           st.m.as<double>(), st.hprev.as<double>(), ctx->va.as<double>(), ctx->vh.as<double>(), ct);
-    } else {
-        hipLaunchKernelGGL(loop_pass1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, npad, k, d9,
-                           ctx->nbr.as<int>(), p.p1, st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(),
-                           st.hprev.as<double>(), ctx->qorder, ctx->rho.as<double>(), ctx->rhod.as<double>(),
-                           ctx->nden.as<double>(), ctx->G.as<double>(), p.p2);
-        hipLaunchKernelGGL(loop_pass2_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, npad, k, ctx->nbr.as<int>(),
-                           p.p1, p.p2, st.m.as<double>(), st.hprev.as<double>(), ctx->qorder, ctx->va.as<double>(),
-                           ctx->vh.as<double>(), ct);
-    }
+    SPHX_TRY(loop_pass1_launch(ctx, n, k, d, st, st.hprev.as<double>()));
+    SPHX_TRY(loop_pass2_launch(ctx, n, k, st, st.hprev.as<double>(), ct));
+    return SPHX_OK;
+}
+
+// ---- the loop-form sums on caller-order device arrays (owned + ghosts): multigpu.py, forms = "loop" ----------
+// The caller's arrays are gathered into sorted order (ctx->alt), the step's kernels run on them, and the owned
+// particles' results are scattered back to caller order.  Ghost neighbours need, beside their state, E (del_pressure,
+// nsc:755), their kNN radius (dust_density, nsc:704) and their density (artificial_viscosity, nsc:803): three halo phases.
+struct DevGatherArgs {
+    int n;
+    const int* perm;                         // sorted -> caller
+    const double *pos, *vel, *m, *T, *mu, *gam, *pt, *E;
+    double *x, *y, *z, *vx, *vy, *vz, *sm, *sT, *smu, *sgam, *spt, *sE;
+};
+__global__ __launch_bounds__(256) void dev_gather_state_kernel(DevGatherArgs a) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n) return;
+    const size_t c = (size_t)a.perm[s];
+    a.x[s] = a.pos[3 * c]; a.y[s] = a.pos[3 * c + 1]; a.z[s] = a.pos[3 * c + 2];
+    a.vx[s] = a.vel[3 * c]; a.vy[s] = a.vel[3 * c + 1]; a.vz[s] = a.vel[3 * c + 2];
+    a.sm[s] = a.m[c]; a.sT[s] = a.T[c]; a.smu[s] = a.mu[c]; a.sgam[s] = a.gam[c]; a.spt[s] = a.pt[c]; a.sE[s] = a.E[c];
+}
+// dst_sorted[s] = src_caller[perm[s]], or 0 for ghosts when owned_only
+__global__ __launch_bounds__(256) void dev_to_sorted_kernel(int n, const int* perm, int n_active, int owned_only,
+                                                            const double* src, double* dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int c = perm[s];
+    dst[s] = (owned_only && c >= n_active) ? 0.0 : src[c];
+}
+__global__ __launch_bounds__(256) void dev_rho_to_records_kernel(int n, const int* perm, const double* rho, RecP2* p2) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) p2[s].rho = rho[perm[s]];
+}
+// caller[perm[s]] = sorted[s] for owned particles, w doubles per particle
+__global__ __launch_bounds__(256) void dev_to_caller_kernel(int n, const int* perm, int n_active, int w,
+                                                            const double* src, double* dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int c = perm[s];
+    if (c >= n_active) return;
+    for (int q = 0; q < w; ++q) dst[(size_t)c * w + q] = src[(size_t)s * w + q];
+}
+#define NEEDD(p) do { if (!(p)) return sphx_set_err(ctx, SPHX_E_ARG, "%s: argument %s is NULL", __func__, #p); } while (0)
+
+extern "C" int sphx_dev_loop_prep(sphx_ctx* ctx, const double* pos, const double* vel, const double* mass,
+                                  const double* T, const double* mu, const double* gamma, const double* ptype,
+                                  const double* E_internal, double d) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDD(pos); NEEDD(vel); NEEDD(mass); NEEDD(T); NEEDD(mu); NEEDD(gamma); NEEDD(ptype); NEEDD(E_internal);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_prep before sphx_dev_search");
+    if (!(d > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_loop_prep: d must be positive");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    StateArrays& st = ctx->alt;
+    DevBuf* bufs[] = {&st.x, &st.y, &st.z, &st.vx, &st.vy, &st.vz, &st.m, &st.T, &st.mu, &st.gam, &st.ptype, &st.E,
+                      &st.hprev, &st.ax};
+    for (DevBuf* b : bufs) SPHX_TRY(sphx_ensure(ctx, *b, (size_t)n * sizeof(double)));
+    DevGatherArgs g;
+    g.n = (int)n; g.perm = ctx->map_perm;
+    g.pos = pos; g.vel = vel; g.m = mass; g.T = T; g.mu = mu; g.gam = gamma; g.pt = ptype; g.E = E_internal;
+    g.x = st.x.as<double>(); g.y = st.y.as<double>(); g.z = st.z.as<double>();
+    g.vx = st.vx.as<double>(); g.vy = st.vy.as<double>(); g.vz = st.vz.as<double>();
+    g.sm = st.m.as<double>(); g.sT = st.T.as<double>(); g.smu = st.mu.as<double>(); g.sgam = st.gam.as<double>();
+    g.spt = st.ptype.as<double>(); g.sE = st.E.as<double>();
+    hipLaunchKernelGGL(dev_gather_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g);
     HIPCHK(hipGetLastError());
+    ctx->loop_d = d;
+    return loop_prep_launch(ctx, n, d, st);
+}
+
+extern "C" int sphx_dev_loop_pass1(sphx_ctx* ctx, const double* h_complete, double* rho, double* rho_dust, double* nden,
+                                   double* delp) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDD(h_complete);
+    if (!ctx->map_perm || !(ctx->loop_d > 0.0)) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_pass1 before sphx_dev_loop_prep");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    StateArrays& st = ctx->alt;
+    // the neighbours' radii (sorted) for pass 1; the owned particles' own radii (ghosts 0: no crossing-time vote) for pass 2
+    hipLaunchKernelGGL(dev_to_sorted_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive, 0,
+                       h_complete, st.hprev.as<double>());
+    hipLaunchKernelGGL(dev_to_sorted_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive, 1,
+                       h_complete, st.ax.as<double>());
+    SPHX_TRY(loop_pass1_launch(ctx, n, ctx->k, ctx->loop_d, st, st.hprev.as<double>()));
+    struct O { double* dst; const double* src; int w; } outs[] = {{rho, ctx->rho.as<double>(), 1}, {rho_dust, ctx->rhod.as<double>(), 1},
+                                                                   {nden, ctx->nden.as<double>(), 1}, {delp, ctx->G.as<double>(), 3}};
+    for (O& o : outs)
+        if (o.dst)
+            hipLaunchKernelGGL(dev_to_caller_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm,
+                               ctx->map_nactive, o.w, o.src, o.dst);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_accel, double* visc_heat,
+                                   double* ct_out) {
+    if (!ctx) return SPHX_E_ARG;
+    NEEDD(rho_complete);
+    if (!ctx->map_perm || !(ctx->loop_d > 0.0)) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_pass2 before sphx_dev_loop_prep");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    StateArrays& st = ctx->alt;
+    hipLaunchKernelGGL(dev_rho_to_records_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, rho_complete,
+                       ctx->lrec_v.as<RecP2>());
+    u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
+    SPHX_TRY(sphx_prime_ct(ctx, ct));
+    ctx->ct_primed = false;
+    SPHX_TRY(loop_pass2_launch(ctx, n, ctx->k, st, st.ax.as<double>(), ct));
+    if (visc_accel)
+        hipLaunchKernelGGL(dev_to_caller_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive,
+                           3, ctx->va.as<double>(), visc_accel);
+    if (visc_heat)
+        hipLaunchKernelGGL(dev_to_caller_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive,
+                           1, ctx->vh.as<double>(), visc_heat);
+    HIPCHK(hipGetLastError());
+    if (ct_out)   // the positive double whose bits are the minimum (+inf = none found)
+        HIPCHK(hipMemcpyAsync(ct_out, ct, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return SPHX_OK;
 }

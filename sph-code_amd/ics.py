@@ -143,6 +143,17 @@ def cfl_dt(state, k=40, courant=0.25):
     return float(courant * hbar / (vmax + cs))
 
 
+def loop_d(state, k=40, sample=200000):
+    """The driver's global d (drv:67-68) for a synthetic IC: chosen so that the loop forms' mass-derived smoothing
+    length h(m) = (m/m_0)^(1/3) d (nsc:675) is the median kNN radius of the cloud (estimated on a subsample)."""
+    from scipy.spatial import cKDTree
+    pts = state["points"]
+    n = len(pts)
+    sub = pts[:: max(1, n // sample)]
+    hs = cKDTree(sub).query(sub, k=min(k, len(sub)))[0][:, -1] * (len(sub) / n) ** (1. / 3.)
+    return float(np.median(hs) / np.median((state["mass"] / 10 ** 1.5 / SOLAR) ** (1. / 3.)))
+
+
 def dusty_sphere(n, seed=12350, dust_frac=0.05, **kw):
     """C1 with a fraction of the particles turned into dust SPH particles (particle_type 2,
     drv:127,150-152): exercises dust density and the gas-dust drag (nsc:719-742)."""

@@ -293,6 +293,40 @@ class LibBackend:
                                                    self._p(red2), 1 if first else 0, float(fixed_dt), self._p(dt)))
         return dt
 
+    # ---- the loop forms of the reference's time loop (drv:451-458) on owned + ghost arrays ----
+    def loop_prep(self, pos, vel, m, T, mu, gam, ptype, E, d):
+        self._keep = (pos, vel, m, T, mu, gam, ptype, E)
+        self._chk(self.lib.sphx_dev_loop_prep(self.ctx.h, *[self._p(t) for t in self._keep], float(d)))
+
+    def loop_pass1(self, h_complete):
+        n, dev = self.n_total, self.device
+        rho = torch.empty(n, dtype=torch.float64, device=dev)
+        rhod = torch.empty(n, dtype=torch.float64, device=dev)
+        nden = torch.empty(n, dtype=torch.float64, device=dev)
+        delp = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        self._chk(self.lib.sphx_dev_loop_pass1(self.ctx.h, self._p(h_complete), self._p(rho), self._p(rhod), self._p(nden),
+                                               self._p(delp)))
+        return rho, rhod, nden, delp
+
+    def loop_pass2(self, rho_complete):
+        n, dev = self.n_total, self.device
+        va = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        vh = torch.empty(n, dtype=torch.float64, device=dev)
+        ct = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._chk(self.lib.sphx_dev_loop_pass2(self.ctx.h, self._p(rho_complete), self._p(va), self._p(vh), self._p(ct)))
+        return va, vh, ct
+
+    def integrate_loop(self, n_owned, pos, vel, acc, E, T, m, mu, gam, ptype, delp, rho, va, vh, dt, red2=None,
+                       first=False, fixed_dt=0.0):
+        """drv:460-491 on the loop forms' outputs; red2 given: verdict and dt on the device -> dt as a (1,) tensor."""
+        dt_t = torch.empty(1, dtype=torch.float64, device=self.device) if red2 is not None else None
+        self._chk(self.lib.sphx_dev_integrate_loop(self.ctx.h, n_owned, self._p(pos), self._p(vel), self._p(acc),
+                                                   self._p(E), self._p(T), self._p(m), self._p(mu), self._p(gam),
+                                                   self._p(ptype), self._p(delp), self._p(rho), self._p(va), self._p(vh),
+                                                   self._p(red2), 1 if first else 0, float(fixed_dt), float(dt),
+                                                   self._p(dt_t)))
+        return dt_t
+
     def integrate(self, n_owned, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
         self._chk(self.lib.sphx_dev_integrate(self.ctx.h, n_owned, self._p(pos), self._p(vel), self._p(acc),
                                               self._p(E), self._p(T), self._p(m), self._p(mu), self._p(gam),
@@ -315,7 +349,15 @@ class DistributedSim:
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
     def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
-                 halo_scale=1.15, skin_frac=0.15, need_grid=96, migrate_every=4):
+                 halo_scale=1.15, skin_frac=0.15, need_grid=96, migrate_every=4, forms="hydro_update", d=None):
+        """forms: the sums of the step - "hydro_update" (nsc:556-671; four halo phases) or "loop", the loop forms the
+        reference's time loop calls (drv:451-458, smoothing length from the driver's global `d`, drv:68; three halo
+        phases: state + E, h_j, rho_j - no Pi_j)."""
+        if forms not in ("hydro_update", "loop"):
+            raise ValueError("forms must be 'hydro_update' or 'loop'")
+        if forms == "loop" and not (d is not None and d > 0):
+            raise ValueError("forms='loop' needs the driver's global d (code_running.py:67-68)")
+        self.forms, self.d = forms, (float(d) if d is not None else None)
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
@@ -606,10 +648,15 @@ class DistributedSim:
             hint_owned = s["h"]
             mean_h = self.hmean_prev
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
+            loop = self.forms == "loop"
             state_fields = [s["pos"], s["vel"], s["m"], s["T"], s["mu"], s["gam"], s["ptype"], s["h"]]
+            if loop:
+                state_fields.append(s["E"])               # del_pressure reads the neighbour's E (nsc:755)
             with self._sec("halo_state"):
                 g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
-                pos, vel, m, T, mu, gam, ptype, hint = self._regroup(None, no, g, state_fields)
+                regrouped = self._regroup(None, no, g, state_fields)
+                pos, vel, m, T, mu, gam, ptype, hint = regrouped[:8]
+                E_all = regrouped[8] if loop else None
             with self._sec("search"):
                 h = be.search(pos, no, hint, mean_h)
             f64 = dict(dtype=torch.float64, device=h.device)
@@ -621,7 +668,16 @@ class DistributedSim:
             # ---- halo phases 2-4: 8 B per ghost, received straight into the tail of the (n_total,)
             # array the library just filled for the owned particles ----------------------------
             tail = lambda a: a[no:].view(ng, 1)
-            with self._sec("sums+halo_scalars"):
+            if loop:
+                with self._sec("sums+halo_scalars"):
+                    self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)    # h_j (nsc:711)
+                    be.loop_prep(pos, vel, m, T, mu, gam, ptype, E_all, self.d)
+                    rho, rhod, nden, delp = be.loop_pass1(h)
+                    self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)  # rho_j (nsc:803)
+                    va, vh, ct = be.loop_pass2(rho)
+                    ha = None
+            else:
+              with self._sec("sums+halo_scalars"):
                 self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)        # h_j
                 be.prep(pos, vel, m, h, T, mu, gam, ptype)
                 rho, nden, ha = be.density()
@@ -661,8 +717,13 @@ class DistributedSim:
                 # the update is launched before the host learns the verdict: the kernel itself leaves the state
                 # alone when the step has to be redone, and works out dt from the reduced crossing time
                 red_dev = red if red.device == h.device else red.to(h.device)
-                dt_t = be.integrate_auto(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"],
-                                         s["ptype"], ha, va, vh, red_dev.contiguous(), self.first, fixed_dt)
+                if loop:
+                    dt_t = be.integrate_loop(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"],
+                                             s["ptype"], delp, rho, va, vh, 0.0, red2=red_dev.contiguous(),
+                                             first=self.first, fixed_dt=fixed_dt)
+                else:
+                    dt_t = be.integrate_auto(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"],
+                                             s["ptype"], ha, va, vh, red_dev.contiguous(), self.first, fixed_dt)
                 vals = torch.cat([red_dev, loc, dt_t]).tolist()
             else:
                 vals = out4.tolist() if (fused and red.data_ptr() == out4.data_ptr()) else torch.cat([red, loc]).tolist()
@@ -688,8 +749,12 @@ class DistributedSim:
                 dt = self.DT_0 / 10. if self.first else max(self.DT_0 / 5., min(self.DT_0 * 2., ctv))
                 if ctv > self.MAX_AGE:
                     dt = self.MAX_AGE / 100.
-            be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
-                         ha, va, vh, dt)
+            if self.forms == "loop":
+                be.integrate_loop(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
+                                  delp, rho, va, vh, dt)
+            else:
+                be.integrate(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"], s["ptype"],
+                             ha, va, vh, dt)
         self.host_ms["dt+integrate"] = self.host_ms.get("dt+integrate", 0.0) + (time.perf_counter() - t_dt) * 1e3
         s["h"] = h[:no].contiguous()
         self.last = dict(rho=rho[:no], nden=nden[:no], visc_heat=vh[:no])
@@ -789,14 +854,40 @@ def bench_main(args, rank, local_rank, world):
         dist.init_process_group(backend, rank=rank, world_size=world)
         comm_dev = torch.device("cpu")
     n_global = args.n * world                       # weak scaling: fixed particles per GPU
-    scale = ics.bench_size_scale(n_global)          # keeps the reference's scheme in its stable regime
-    if getattr(args, "natural_size", False) and n_global > 1e6:
-        scale = (n_global / 1e6) ** (1. / 3.)
+    forms = getattr(args, "forms", None) or "hydro_update"
+    if forms == "loop" and args.workload == "uniform_cube":
+        # BASELINE configs[3] as written: the reference's own IC (uniform cube of side 1.25e6 AU, drv:62,132) at its
+        # natural size, stepped by the loop forms its time loop calls (drv:451-458) - stable, no dilution
+        scale, dilution = 1.0, "none (natural size)"
+    else:
+        scale = ics.bench_size_scale(n_global)      # keeps the reference's hydro_update scheme in its stable regime
+        dilution = "x%.3g in length (ics.bench_size_scale)" % scale
+        if getattr(args, "natural_size", False) and n_global > 1e6:
+            scale = (n_global / 1e6) ** (1. / 3.)
+            dilution = "constant density: x%.3g in length" % scale
     state = ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale)
+    d_loop = ics.loop_d(state, args.k) if forms == "loop" else None
+    # the same workload at the per-GPU size on ONE GPU through the fused single-GPU loop (rank 0, before the decomposed
+    # run): the denominator a scaling efficiency for THIS workload needs, measured in the same process
+    single = None
+    if rank == 0 and world > 1 and os.environ.get("SPHX_BENCH_SINGLE", "1") != "0":
+        from .sim import Simulation
+        s1 = ics.WORKLOADS[args.workload](args.n, light=True, size_scale=1.0 if dilution.startswith("none") else ics.bench_size_scale(args.n))
+        sim1 = Simulation(s1, n_neigh=args.k, device=dev_index, forms=forms, d=ics.loop_d(s1, args.k) if forms == "loop" else None,
+                          clip_grad=getattr(args, "clip_grad", False))
+        sim1.step(3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sim1.step(10)
+        torch.cuda.synchronize()
+        single = {"ms_per_step": (time.perf_counter() - t1) / 10 * 1e3, "particles": args.n,
+                  "particle_steps_per_s": args.n * 10 / (time.perf_counter() - t1)}
+        sim1.ctx.close()
+        del sim1, s1
     mine, lo, hi = decompose_state(state, world, rank)
     del state
     be = LibBackend(dev_index, k=args.k, clip_grad=getattr(args, "clip_grad", False))
-    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev)
+    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev, forms=forms, d=d_loop)
     for _ in range(args.warmup):
         sim.step()
     sim.ex.bytes_sent = 0
@@ -831,11 +922,13 @@ def bench_main(args, rank, local_rank, world):
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s sphere, N=%d (%d per GPU), K=%d, fp64, poly6 kernel, viscosity on"
+            "config": {"workload": "%s, N=%d (%d per GPU), K=%d, fp64, poly6 kernel, viscosity on"
                                    % (args.workload, int(total), args.n, args.k),
                        "particles_per_gpu": args.n,
-                       "decomposition": "recursive coordinate bisection, %d regions, 4-phase p2p halo" % world,
-                       "backend": backend, "cloud_size_scale": scale},
+                       "decomposition": "recursive coordinate bisection, %d regions, %d-phase p2p halo" % (world, 3 if forms == "loop" else 4),
+                       "backend": backend, "cloud_size_scale": scale, "dilution": dilution,
+                       "forms": forms + (" (the reference's time loop: nsc.density, del_pressure, artificial_viscosity ...)" if forms == "loop" else "")},
+            "single_gpu_same_workload": single,
             "state_check": {"finite": float(chk[1]) == 0.0, "max_speed_m_s": float(chk[0]),
                             "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
             "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "knn_kernel<0,2> (rank 0)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,

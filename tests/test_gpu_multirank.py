@@ -45,7 +45,30 @@ def test_one_rank_device_api_matches_fused_step():
         np.testing.assert_allclose(b[key][order], a[key], rtol=1e-13, atol=0, err_msg=key)
 
 
-def _worker(rank, world, port, n, nsteps, workload, out_dir):
+def test_one_rank_device_api_matches_fused_step_in_loop_form_mode():
+    """forms='loop' (the reference's time loop: nsc.density, del_pressure, artificial_viscosity on the step's list):
+    the device-pointer protocol of the multi-GPU driver against the fused single-GPU loop, bit for bit."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd import multigpu as mg
+    from sph_code_amd.sim import Simulation
+    n, nsteps = 20000, 4
+    state = ics.uniform_cube(n, light=True)
+    d = ics.loop_d(state, K)
+    sim = Simulation(state, n_neigh=K, forms="loop", d=d)
+    mine, lo, hi = mg.decompose_state(state, 1, 0)
+    dsim = mg.DistributedSim(mine, lo, hi, mg.LibBackend(0, k=K), 0, 1, device="cuda:0", forms="loop", d=d)
+    for _ in range(nsteps):
+        sim.step(1)
+        dsim.step()
+    a = sim.download()
+    b = dsim.owned_numpy()
+    order = np.argsort(b["gid"])
+    assert a["dt"] == pytest.approx(b["dt"], rel=1e-15)
+    for key in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities"):
+        np.testing.assert_allclose(b[key][order], a[key], rtol=1e-13, atol=0, err_msg=key)
+
+
+def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -54,7 +77,8 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir):
     from sph_code_amd import multigpu as mg
     state = ics.WORKLOADS[workload](n, light=True)
     mine, lo, hi = mg.decompose_state(state, world, rank)
-    sim = mg.DistributedSim(mine, lo, hi, mg.LibBackend(0, k=K), rank, world, device="cuda:0", comm_device="cpu")
+    kw = dict(forms="loop", d=ics.loop_d(state, K)) if forms == "loop" else {}
+    sim = mg.DistributedSim(mine, lo, hi, mg.LibBackend(0, k=K), rank, world, device="cuda:0", comm_device="cpu", **kw)
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
@@ -81,6 +105,34 @@ def test_ranks_sharing_one_gpu_match_oracle(world, workload, tmp_path):
     ref = ics.WORKLOADS[workload](n, light=True)
     for it in range(nsteps):
         ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0))
+    assert float(parts[0]["dt"]) == pytest.approx(ref["dt"], rel=1e-12)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-11)
+    assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * np.max(np.abs(ref["points"]))
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
+    assert sum(p["stats"][0] for p in parts) > 0
+
+
+def test_two_ranks_sharing_one_gpu_loop_forms_on_the_reference_ic(tmp_path):
+    """BASELINE configs[3] in small on the GPU: uniform cube (drv:62,132), loop-form step mode, two ranks (gloo
+    carries the three halo phases) against the single-domain oracle.step_loop."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    n, nsteps, world = 12000, 3, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, nsteps, "uniform_cube", str(tmp_path), "loop"), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    gid = np.concatenate([p["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    got = {k_: np.concatenate([p[k_] for p in parts])[order]
+           for k_ in ("points", "velocities", "E_internal", "sizes", "densities")}
+    ref = ics.uniform_cube(n, light=True)
+    d = ics.loop_d(ref, K)
+    ref["f_un"] = None
+    for it in range(nsteps):
+        ref = orc.step_loop(ref, d, n_neigh=K, eps=0.0, first=(it == 0))
     assert float(parts[0]["dt"]) == pytest.approx(ref["dt"], rel=1e-12)
     np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-12)
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-11)

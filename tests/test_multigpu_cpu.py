@@ -58,6 +58,41 @@ class OracleBackend:
         out = self._hu(rho_in=self.rho_c, Bj_in=bw_complete.numpy())
         return torch.from_numpy(out[1].copy()), torch.from_numpy(out[2].copy())
 
+    # ---- the loop forms (drv:451-458) ----
+    def loop_prep(self, pos, vel, m, T, mu, gam, ptype, E, d):
+        self.la = [t.numpy() for t in (pos, vel, m, T, mu, gam, ptype, E)]
+        self.d = d
+
+    def loop_pass1(self, h_complete):
+        o = self.orc
+        pos, vel, m, T, mu, gam, ptype, E = self.la
+        self.h = h_complete.numpy()
+        rho = o.density(pos, m, ptype, self.nb, self.d)
+        rhod = o.dust_density(pos, m, self.nb, ptype, self.h)
+        nden = o.num_dens(m, pos, mu, self.nb, self.d)
+        delp = o.del_pressure(pos, m, ptype, self.nb, E, gam, self.d)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        return f(rho), f(rhod), f(nden), f(delp)
+
+    def loop_pass2(self, rho_complete):
+        o = self.orc
+        pos, vel, m, T, mu, gam, ptype, E = self.la
+        av = o.artificial_viscosity(self.nb, pos, ptype, self.h, m, rho_complete.numpy(), vel, T, gam, mu, self.d)
+        pt = ptype.copy(); pt[self.no:] = 1.0                    # ghosts do not vote on dt
+        ct = o.crossing_time(self.nb, vel, self.h, pt)
+        from sph_code_amd.multigpu import HUGE_CT
+        ctv = HUGE_CT if ct == o.DT_0 / 10. else ct - 0.0001
+        return torch.from_numpy(np.ascontiguousarray(av[0])), torch.from_numpy(np.ascontiguousarray(av[1])), ctv
+
+    def integrate_loop(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, delp, rho, va, vh, dt, red2=None, first=False,
+                       fixed_dt=0.0):
+        o = self.orc
+        n = lambda t: t.numpy()[:no]
+        pa, visc = o.assemble_loop(n(delp), n(rho), None, n(ptype), n(va), None)
+        p, v, tot, En, Tn = o.leapfrog(n(pos), n(vel), n(acc), n(E), n(m), n(mu), n(gam), pa, visc, n(vh), dt)
+        for dst, src in ((pos, p), (vel, v), (acc, tot), (E, En), (T, Tn)):
+            dst[:no] = torch.from_numpy(np.ascontiguousarray(src))
+
     def integrate(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
         n = lambda t: t.numpy()[:no]
         p, v, tot, En, Tn = self.orc.integrate(n(pos), n(vel), n(acc), n(E), n(m), n(mu), n(gam), n(ptype),
@@ -84,7 +119,10 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, sim_kw=None):
     from sph_code_amd import multigpu as mg
     state = ics.WORKLOADS[workload](n, light=True)
     mine, lo, hi = mg.decompose_state(state, world, rank)
-    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **(sim_kw or {}))
+    sim_kw = dict(sim_kw or {})
+    if sim_kw.get("forms") == "loop":
+        sim_kw["d"] = ics.loop_d(state, K)
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **sim_kw)
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
@@ -218,3 +256,25 @@ def test_world2_halo_too_thin_is_detected_and_redone(tmp_path):
     np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-12)
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
     assert got["dt"][0] == got["dt"][1] == pytest.approx(ref["dt"], rel=1e-14)
+
+
+def test_world2_gloo_loop_forms_on_the_reference_ic(tmp_path):
+    """BASELINE configs[3] in small: the reference's own IC (uniform cube, drv:62,132) stepped by the loop forms its
+    time loop calls (drv:451-458), two ranks over gloo - three halo phases (state + E, h_j, rho_j) - against the
+    single-domain oracle.step_loop (whose loop forms the golden vectors pin)."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    n, nsteps = 3000, 4
+    got = _run_world(2, n, nsteps, "uniform_cube", tmp_path, sim_kw=dict(forms="loop"))
+    ref = ics.uniform_cube(n, light=True)
+    d = ics.loop_d(ref, K)
+    ref["f_un"] = None
+    for it in range(nsteps):
+        ref = orc.step_loop(ref, d, n_neigh=K, eps=0.0, first=(it == 0))
+    assert got["dt"][0] == got["dt"][1] == pytest.approx(ref["dt"], rel=1e-14)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-13)
+    np.testing.assert_allclose(got["velocities"], ref["velocities"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-12)
+    assert got["stats"][0] > 0
