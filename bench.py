@@ -25,34 +25,52 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic bytes per particle-step, K = 40, int32 indices internally
 B_SEARCH = 24 + 4 * 40 + 8       # R pos, W idx, W h                       = 192
 B_STEP_CORE = 1248               # search + 3 passes + integrator
+B_STEP_SPECIES = 1488            # + species pass (R f_un 120, W F 120)
 
 
-def measured_traffic(n, k):
-    """HBM-side bytes per kNN launch from the committed PMC profile of this same command
-    (profiles/latest_knn_traffic.json), or None when the profile is for another size."""
+def search_profile(n, k):
+    """Counters of the search launches from the committed rocprofv3 --pmc profile of this same command
+    (profiles/latest_search_profile.json: HBM-side bytes, VALU issue fraction), or {} when it is for another size.
+    These are PROFILED numbers of the same build, not measured in this run - labelled so in the bench line."""
     try:
-        with open(os.path.join(ROOT, "profiles", "latest_knn_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "latest_search_profile.json")) as f:
             t = json.load(f)
         if int(t["n"]) == int(n) and int(t["k"]) == int(k):
-            return float(t["traffic_bytes_per_launch"])
+            return t
     except Exception:
         pass
-    return None
+    return {}
 
 
 def cpu_baseline(workload, n_cpu, k):
-    """The oracle (NumPy/SciPy restatement of the reference, oracle/sph_oracle.py) timed on this
-    box's host cores on a bounded sample of the same workload: one step at n_cpu particles."""
+    """The oracle (NumPy/SciPy restatement of the reference, oracle/sph_oracle.py) timed on this box's host cores on
+    bounded samples: one step of the bench workload at n_cpu particles on 1 thread (the headline: the reference is
+    single-threaded Python), the same with the tree query on every core, and BASELINE configs[0] (1e4 particles,
+    10 steps)."""
     from oracle import sph_oracle as orc
     import sph_code_amd.ics as ics
     s = ics.WORKLOADS[workload](n_cpu)
     t0 = time.perf_counter()
     orc.step(s, n_neigh=k, eps=0.1, first=True, workers=1)      # eps=0.1: the reference's call
     dt = time.perf_counter() - t0
-    return {"value": n_cpu / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-            "sample": "1 step of the %s workload at N=%d (NumPy/SciPy oracle, 1 thread, eps=0.1 cKDTree "
-                      "as the reference calls it); host has %d cores" % (workload, n_cpu, os.cpu_count()),
-            "seconds": dt}
+    out = {"value": n_cpu / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+           "sample": "1 step of the %s workload at N=%d (NumPy/SciPy oracle, 1 thread, eps=0.1 cKDTree "
+                     "as the reference calls it); host has %d cores" % (workload, n_cpu, os.cpu_count()),
+           "seconds": dt}
+    t0 = time.perf_counter()
+    orc.step(s, n_neigh=k, eps=0.1, first=True, workers=-1)
+    dt2 = time.perf_counter() - t0
+    c1 = ics.uniform_sphere(10000)
+    t0 = time.perf_counter()
+    for it in range(10):
+        c1 = orc.step(c1, n_neigh=k, eps=0.1, first=(it == 0), workers=1)
+    dt3 = time.perf_counter() - t0
+    out["also"] = [
+        {"value": n_cpu / dt2, "unit": "particle-steps/s", "cores": os.cpu_count(), "seconds": dt2,
+         "sample": "the same step with cKDTree.query(workers=-1): the tree query on every core, the NumPy sums on one"},
+        {"value": 1e4 * 10 / dt3, "unit": "particle-steps/s", "cores": 1, "seconds": dt3,
+         "sample": "BASELINE configs[0]: 1e4-particle uniform sphere, 10 leapfrog steps, 1 thread"}]
+    return out
 
 
 def main():
@@ -77,6 +95,9 @@ def main():
                     help="physics option sphx_set_clip_grad (not the reference's hydro_update arithmetic; same cost)")
     ap.add_argument("--natural-size", action="store_true",
                     help="do not enlarge the cloud beyond 1e6 particles (ics.bench_size_scale)")
+    ap.add_argument("--species", action="store_true",
+                    help="carry f_un and run the species pass (nsc:624-627) in every step, with the per-particle "
+                         "metallicity and the AGB dust yields fused in (BASELINE configs[4]; 1488-B model)")
     ap.add_argument("--gravity", default=None, choices=["direct", "tree"],
                     help="self-gravity in the timed step (off in the BASELINE metric; DESIGN 5.7)")
     args = ap.parse_args()
@@ -116,8 +137,16 @@ def main():
     scale = (args.n / 1e6) ** (1. / 3.) if (args.natural_size and args.n > 1e6) else ics.bench_size_scale(args.n)
     state = ics.WORKLOADS[args.workload](args.n, size_scale=scale)
     d_loop = ics.loop_d(state, args.k) if args.forms == "loop" else None
+    agb_table = None
+    if args.species:
+        import sph_code_amd.agb as agb_mod
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "agb_reference.npz")
+        z = np.load(gold)                                    # the reference's AGB tables as fitted knots (data)
+        agb_table = agb_mod.splines_from_arrays(z["tx"], z["ty"], z["coeffs"], z["mapto"], float(z["divisor"]))
+        if state.get("f_un") is None:
+            raise SystemExit("--species needs a workload that carries f_un (two_phase, dusty_sphere)")
     sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad,
-                     forms=args.forms, d=d_loop)
+                     forms=args.forms, d=d_loop, with_species=args.species, agb=agb_table)
     fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0
     sim.step(args.warmup, fixed_dt=fixed_dt)
     sim.reset_stats()
@@ -133,31 +162,42 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = args.n * args.steps / dt
-    ms_search = st["ms_search"] / max(st["steps"], 1)      # HIP events on the library's stream
+    ms_search = st["ms_search"] / max(st["steps"], 1)      # HIP events on the library's stream, around the search launches
     achieved = B_SEARCH * args.n / (ms_search * 1e-3) / 1e9
+    prof = search_profile(args.n, args.k)
+    b_step = B_STEP_SPECIES if args.species else B_STEP_CORE
     out = {
         "metric": "particle-steps/sec + achieved HBM GB/s, 10^6-particle 3D sphere, 1/2/4/8 GPUs",
         "value": value, "unit": "particle-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s sphere, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
+        "config": {"workload": "%s, N=%d, K=%d, fp64, poly6 kernel, viscosity on" %
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
                    "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale,
-                   "forms": args.forms,
+                   "forms": args.forms, "species_pass": bool(args.species),
                    "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)"},
         # the reference's scheme can diverge: evidence that the timed window was a sane flow
         "state_check": {"finite": sane, "max_speed_m_s": vmax,
                         "max_drift_per_step_in_mean_h": vmax * float(final["dt"]) / float(final["sizes"].mean())},
-        "roofline": {"bound": "hbm", "kernel": "knn_kernel<0,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.n, args.k),
+        # The dominant kernel is the search (knn_group_kernel + the list-mode knn_kernel for what it hands on).  SURVEY
+        # 8(d) prices it against HBM (achieved / peak / frac below, live from this run's events); the counters say it
+        # is bound by instruction issue and latency, not by HBM: `limiter` and the profiled fractions name that.
+        "roofline": {"bound": "hbm", "kernel": "search: knn_group_kernel + knn_kernel<0,1,1> (list mode)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": prof.get("traffic_bytes_per_launch"),
+                     "traffic_source": prof.get("source", None),
+                     "limiter": "VALU issue + LDS/memory latency (L2 hit rate ~98 %; not HBM)",
+                     "valu_issue_frac": prof.get("valu_issue_frac"),
+                     "valu_wave_instr_per_query": prof.get("valu_wave_instr_per_query"),
+                     "profiled_counters_source": prof.get("source", None),
                      "algorithmic_bytes_per_launch": B_SEARCH * args.n,
                      "algorithmic_bytes_per_particle": B_SEARCH, "kernel_ms": ms_search},
-        "step_model": {"algorithmic_bytes_per_particle_step": B_STEP_CORE,
-                       "achieved_GBs": B_STEP_CORE * value / 1e9,
-                       "frac_of_hbm_peak": B_STEP_CORE * value / 1e9 / HBM_PEAK_GBS},
+        "step_model": {"algorithmic_bytes_per_particle_step": b_step,
+                       "achieved_GBs": b_step * value / 1e9,
+                       "frac_of_hbm_peak": b_step * value / 1e9 / HBM_PEAK_GBS},
         "per_pass_ms": {k_: st[k_] / max(st["steps"], 1) for k_ in
-                        ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_pi", "ms_visc",
+                        ("ms_grid", "ms_search", "ms_prep", "ms_density", "ms_species", "ms_pi", "ms_visc",
                          "ms_integrate", "ms_gravity", "ms_total")},
         "search": {"candidates_per_particle_step": st["candidates"] / max(st["steps"], 1) / args.n,
                    "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"],

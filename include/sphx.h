@@ -73,6 +73,7 @@ typedef struct sphx_stats {
     double  cell_size;     /* edge of the last grid's cells                     */
     double  ms_gravity;    /* self-gravity (0 unless sphx_state_set_gravity)    */
     int64_t fallback_queries; /* last step: queries the grouped search left to the general kernel */
+    double  ms_species;    /* species pass of the step (+ metallicity, AGB yields); ms_density excludes it */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -230,6 +231,18 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
  * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
  * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
 int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
+/* Species pass inside the step: when sphx_state_upload was given f_un, every sphx_step (hydro_update mode) also forms
+ * F[s,i] = sum_k m_j/(mu_j amu) [gas_j] f_un[j,s] W (nsc:624-627) on its own neighbour list.  With an AGB table set
+ * (config_helper.py:138-178: nspl degree-1 splines over (metallicity, mass) as sphx_agb_yields takes them; nspl = 0
+ * switches it off) the same pass leaves, without another trip over memory, the per-particle metallicity
+ * Z_i = sum_{s>=6} F[s,i] mu_s / sum_s F[s,i] mu_s (the expression of code_running.py:663 on the smoothed composition)
+ * and the AGB dust yields of config_helper.py:183-189 at (Z_i, m_i) - BASELINE configs[4].
+ * sphx_state_download_species: F (s,n) species-major as nsc:671 returns it, Z (n,), agb_dust (n,s); caller order;
+ * any pointer may be NULL.                                                                                          */
+int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                       const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                       const double* mu_specie, double solar_mass);
+int sphx_state_download_species(sphx_ctx* ctx, double* F, double* Z, double* agb_dust);
 /* Step mode "loop forms": on != 0 makes sphx_step evaluate, on its own neighbour list, exactly what the
  * reference's time loop evaluates (drv:451-458): density, dust_density, num_dens, del_pressure,
  * artificial_viscosity and crossing_time in their loop forms (nsc:673-816; smoothing length

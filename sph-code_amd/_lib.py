@@ -22,7 +22,8 @@ class SphxStats(C.Structure):
                                           "ms_visc", "ms_integrate", "ms_total")] + \
                [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
                                          "rebuild_steps")] + \
-               [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64)]
+               [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64),
+                ("ms_species", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -60,6 +61,9 @@ SIGNATURES = {
     "sphx_leapfrog": (C.c_int, [_P, C.c_int64] + [_D] * 18 + [C.c_double]),
     "sphx_state_upload": (C.c_int, [_P, C.c_int64, C.c_int] + [_D] * 10),
     "sphx_state_set_drag": (C.c_int, [_P, _D, _D]),
+    "sphx_state_set_agb": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D, _D, _D,
+                                     C.POINTER(C.c_int32), C.c_double, _D, C.c_double]),
+    "sphx_state_download_species": (C.c_int, [_P, _D, _D, _D]),
     "sphx_state_set_loop_forms": (C.c_int, [_P, C.c_int, C.c_double]),
     "sphx_set_clip_grad": (C.c_int, [_P, C.c_int]),
     "sphx_state_set_gravity": (C.c_int, [_P, C.c_int, C.c_double]),

@@ -47,13 +47,17 @@ class Spline:
 
 def load_tables(absolute_path_to_AGB, sort_files=True):
     """config_helper.py:152-166 -> (species, metallicity, mass) with values <= 0 set to 1e-30."""
-    files = [f for f in os.listdir(absolute_path_to_AGB) if f != ".DS_Store"]
+    names = os.listdir(absolute_path_to_AGB)
     if sort_files:
-        files = sorted(files)
-    by_metallicity = [np.genfromtxt(os.path.join(absolute_path_to_AGB, f)).T[1:] for f in files]
-    seg = np.swapaxes(by_metallicity, 0, 1).copy()
-    seg[seg <= 0.] = 1e-30
-    return seg
+        names = sorted(names)
+    cube = None                                           # (metallicity, species, mass) while reading
+    for name in names:
+        if name == ".DS_Store":
+            continue
+        yields = np.genfromtxt(os.path.join(absolute_path_to_AGB, name))[:, 1:].T        # column 0 is the stellar mass
+        cube = yields[None] if cube is None else np.concatenate([cube, yields[None]], axis=0)
+    table = np.transpose(cube, (1, 0, 2)).copy()
+    return np.where(table <= 0., 1e-30, table)
 
 
 def fit_tables(species_segregated, s=0.9):
@@ -64,6 +68,12 @@ def fit_tables(species_segregated, s=0.9):
         tx, ty = sp.get_knots()
         out.append(Spline(tx, ty, sp.get_coeffs()))
     return out
+
+
+def splines_from_arrays(tx, ty, coeffs, mapto, divisor=3):
+    """(splines, mapto, divisor) from stored knots / coefficients (one row per spline), e.g. the data a previous
+    interpolate_amounts produced - the form tests/golden/agb_reference.npz keeps them in."""
+    return [Spline(a, b, c_) for a, b, c_ in zip(tx, ty, coeffs)], np.asarray(mapto), divisor
 
 
 def interpolate_amounts(absolute_path_to_nsc, s=0.9, sort_files=True):

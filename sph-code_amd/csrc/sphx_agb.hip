@@ -10,16 +10,12 @@
 #include "sphx_internal.h"
 #pragma clang fp contract(off)
 
-#define AGB_MAX_SPL 32
-#define AGB_MAX_SPEC 32
+#include "sphx_agb.h"
 
 struct AgbArgs {
-    int n, nspl, nspec;
-    const double *mass, *met, *comp, *knots;     // knots: tx | ty | coeffs, flattened
-    int tx_off[AGB_MAX_SPL], ty_off[AGB_MAX_SPL], c_off[AGB_MAX_SPL], ntx[AGB_MAX_SPL], nty[AGB_MAX_SPL];
-    int mapto[AGB_MAX_SPL];
-    double mu[AGB_MAX_SPEC];
-    double divisor, solar;
+    int n;
+    AgbTable t;
+    const double *mass, *met, *comp;
     double *dust, *gas;
 };
 
@@ -40,60 +36,28 @@ __device__ __forceinline__ double np_sum(const double* a, int n) {
     return res;
 }
 
-// interval l (0-based index of the left knot) and the two weights of a degree-1 spline
-__device__ __forceinline__ void agb_weights(const double* t, int nt, double x, int& l, double& w0, double& w1) {
-    const double tb = t[1], te = t[nt - 2];
-    x = x < tb ? tb : x;
-    x = x > te ? te : x;
-    l = 1;
-    while (l < nt - 3 && x >= t[l + 1]) ++l;
-    const double f = 1.0 / (t[l + 1] - t[l]);
-    w0 = f * (t[l + 1] - x);
-    w1 = f * (x - t[l]);
-}
-
 __global__ __launch_bounds__(128) void agb_kernel(AgbArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const double M = a.mass[i], Z = a.met[i];
+    const int nspec = a.t.nspec;
     double dust[AGB_MAX_SPEC];
-    for (int s = 0; s < a.nspec; ++s) dust[s] = 0.0;
-    for (int o = 0; o < a.nspl; ++o) {
-        const double* tx = a.knots + a.tx_off[o];
-        const double* ty = a.knots + a.ty_off[o];
-        const double* c = a.knots + a.c_off[o];
-        const int ny = a.nty[o] - 2;
-        int lx, ly;
-        double wx0, wx1, wy0, wy1;
-        agb_weights(tx, a.ntx[o], Z, lx, wx0, wx1);
-        agb_weights(ty, a.nty[o], M, ly, wy0, wy1);
-        const double* c0 = c + (lx - 1) * ny + (ly - 1);
-        double sp = c0[0] * wx0 * wy0;
-        sp = sp + c0[1] * wx0 * wy1;
-        sp = sp + c0[ny] * wx1 * wy0;
-        sp = sp + c0[ny + 1] * wx1 * wy1;
-        dust[a.mapto[o]] = sp;                         // config_helper.py:185
-    }
-    for (int s = 0; s < a.nspec; ++s) {
-        double d = dust[s] / a.divisor;                // :188
-        d = (d < 0.0) ? 0.0 : d;                       // :189
-        dust[s] = d;
-        a.dust[(size_t)i * a.nspec + s] = d;
-    }
+    agb_dust_yields(a.t, M, Z, dust);
+    for (int s = 0; s < nspec; ++s) a.dust[(size_t)i * nspec + s] = dust[s];
     if (!a.gas) return;
-    const double mass_wd = (0.55 + (M / a.solar - 1.) * 0.45 / (7. - 1.)) * a.solar;     // :182
-    const double gas_mass = M - np_sum(dust, a.nspec) - mass_wd;                          // :191
+    const double mass_wd = (0.55 + (M / a.t.solar - 1.) * 0.45 / (7. - 1.)) * a.t.solar;     // :182
+    const double gas_mass = M - np_sum(dust, nspec) - mass_wd;                          // :191
     double num[AGB_MAX_SPEC], w[AGB_MAX_SPEC];
-    for (int s = 0; s < a.nspec; ++s) num[s] = a.comp[(size_t)i * a.nspec + s] / a.mu[s]; // :194
+    for (int s = 0; s < nspec; ++s) num[s] = a.comp[(size_t)i * nspec + s] / a.t.mu[s]; // :194
     const double ion = num[3] * 0.1, h2 = num[0] * 0.1, h = num[2] * 0.1;                 // :196-198
     num[0] -= h2;
     num[1] += h / 4. + h2 / 2. + ion / 4.;
     num[2] -= h;
     num[3] -= ion;
     num[5] -= ion;
-    for (int s = 0; s < a.nspec; ++s) w[s] = num[s] * a.mu[s];
-    const double tot = np_sum(w, a.nspec);                                               // :206
-    for (int s = 0; s < a.nspec; ++s) a.gas[(size_t)i * a.nspec + s] = w[s] / tot * gas_mass;   // :206,211
+    for (int s = 0; s < nspec; ++s) w[s] = num[s] * a.t.mu[s];
+    const double tot = np_sum(w, nspec);                                               // :206
+    for (int s = 0; s < nspec; ++s) a.gas[(size_t)i * nspec + s] = w[s] / tot * gas_mass;   // :206,211
 }
 
 extern "C" int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, const double* metallicities,
@@ -111,7 +75,7 @@ extern "C" int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, c
     if (!(divisor != 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_agb_yields: divisor is 0");
     HIPCHK(hipSetDevice(ctx->device));
     AgbArgs a;
-    a.n = (int)n; a.nspl = nspl; a.nspec = nspecies;
+    a.n = (int)n; a.t.nspl = nspl; a.t.nspec = nspecies;
     size_t ntx_tot = 0, nty_tot = 0, nc_tot = 0;
     for (int o = 0; o < nspl; ++o) {
         if (ntx[o] < 4 || nty[o] < 4)
@@ -122,12 +86,12 @@ extern "C" int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, c
     }
     size_t ox = 0, oy = ntx_tot, oc = ntx_tot + nty_tot;
     for (int o = 0; o < nspl; ++o) {
-        a.tx_off[o] = (int)ox; a.ty_off[o] = (int)oy; a.c_off[o] = (int)oc;
-        a.ntx[o] = ntx[o]; a.nty[o] = nty[o]; a.mapto[o] = mapto[o];
+        a.t.tx_off[o] = (int)ox; a.t.ty_off[o] = (int)oy; a.t.c_off[o] = (int)oc;
+        a.t.ntx[o] = ntx[o]; a.t.nty[o] = nty[o]; a.t.mapto[o] = mapto[o];
         ox += ntx[o]; oy += nty[o]; oc += (size_t)(ntx[o] - 2) * (nty[o] - 2);
     }
-    for (int s = 0; s < nspecies; ++s) a.mu[s] = mu_specie[s];
-    a.divisor = divisor; a.solar = solar_mass;
+    for (int s = 0; s < nspecies; ++s) a.t.mu[s] = mu_specie[s];
+    a.t.divisor = divisor; a.t.solar = solar_mass;
     const size_t nk = ntx_tot + nty_tot + nc_tot;
     const size_t ns = (size_t)n * nspecies * sizeof(double);
     SPHX_TRY(sphx_ensure(ctx, ctx->in_a, nk * sizeof(double)));
@@ -140,7 +104,7 @@ extern "C" int sphx_agb_yields(sphx_ctx* ctx, int64_t n, const double* masses, c
     HIPCHK(hipMemcpyAsync(kd + ntx_tot + nty_tot, coeffs, nc_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->in_b.p, masses, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->in_c.p, metallicities, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    a.knots = kd; a.mass = ctx->in_b.as<double>(); a.met = ctx->in_c.as<double>();
+    a.t.knots = kd; a.mass = ctx->in_b.as<double>(); a.met = ctx->in_c.as<double>();
     a.comp = nullptr; a.gas = nullptr;
     a.dust = ctx->out_b.as<double>();
     if (gas_out) {

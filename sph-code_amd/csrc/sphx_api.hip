@@ -146,7 +146,8 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->inv, &ctx->scan_tmp, &ctx->bbox_tmp, &ctx->in_a, &ctx->in_b, &ctx->in_c,
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
-                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list};
+                     &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
+                     &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -362,8 +363,16 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     SPHX_TRY(sphx_iota(ctx, n, st.id.as<int>()));
     ctx->s = 0;
     if (f_un) {
-        SPHX_TRY(upload(ctx, st.fun, f_un, (size_t)n * s * sizeof(double)));
+        // rows padded to whole 128-B lines (16 doubles for the reference's 15 species): one aligned line per neighbour
+        // in the species pass, vector copies in the permutation
+        const int sp = (s + 15) & ~15;
+        SPHX_TRY(upload(ctx, ctx->in_d, f_un, (size_t)n * s * sizeof(double)));
+        SPHX_TRY(sphx_ensure(ctx, st.fun, (size_t)n * sp * sizeof(double)));
+        HIPCHK(hipMemsetAsync(st.fun.p, 0, (size_t)n * sp * sizeof(double), ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(st.fun.p, (size_t)sp * sizeof(double), ctx->in_d.p, (size_t)s * sizeof(double),
+                                (size_t)s * sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
         ctx->s = s;
+        ctx->sp = sp;
     }
     HIPCHK(hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream));
     ctx->ct_primed = false;       // SC_CT_BITS was just zeroed: the next pass 2 must prime it again
@@ -373,6 +382,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->npad = sphx_pad64(n);
     ctx->has_state = true;
     ctx->drag = false;
+    ctx->agb_on = false;
     ctx->gravity = 0;
     ctx->loop_forms = 0;
     ctx->list_valid = false;
@@ -547,13 +557,16 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
-        if (ctx->drag)
+        const bool species = ctx->s > 0 && ctx->st.fun.p;      // the species pass reads hydro_update's records (RecA)
+        if (ctx->drag || species)
             SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
                                s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
                                s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
                                s.ptype.as<double>()));
         HIPCHK(hipEventRecord(ev[3], ctx->stream));
         SPHX_TRY(sphx_loop_step_sums(ctx, n, k, ctx->loop_d));
+        HIPCHK(hipEventRecord(ev[9], ctx->stream));
+        if (species) SPHX_TRY(sphx_step_species(ctx, n, k));       // nsc:624-627 (+ metallicity, AGB yields)
         HIPCHK(hipEventRecord(ev[4], ctx->stream));
         HIPCHK(hipEventRecord(ev[5], ctx->stream));
         if (ctx->drag)
@@ -579,6 +592,9 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     }
     HIPCHK(hipEventRecord(ev[3], ctx->stream));
     SPHX_TRY(sphx_pass_density(ctx, n, k));
+    HIPCHK(hipEventRecord(ev[9], ctx->stream));
+    // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un
+    if (ctx->s > 0 && ctx->st.fun.p) SPHX_TRY(sphx_step_species(ctx, n, k));
     HIPCHK(hipEventRecord(ev[4], ctx->stream));
     SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
     HIPCHK(hipEventRecord(ev[5], ctx->stream));
@@ -624,6 +640,13 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
     HIPCHK(hipEventElapsedTime(&mi, ev[8], ev[7]));
     ms[6] = mi;
     st.ms_gravity += mg;
+    {                                             // (ev[9] is recorded between the sums before it and the species pass)
+        float md = 0.f, msp = 0.f;
+        HIPCHK(hipEventElapsedTime(&md, ev[3], ev[9]));
+        HIPCHK(hipEventElapsedTime(&msp, ev[9], ev[4]));
+        ms[3] = md;
+        st.ms_species += msp;
+    }
     st.ms_pi += ms[4]; st.ms_visc += ms[5]; st.ms_integrate += ms[6]; st.ms_total += tot;
     st.steps += 1;
     st.n = ctx->n;
@@ -693,6 +716,88 @@ extern "C" int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, doub
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     if (dt_last) *dt_last = ctx->dt_last;
+    return SPHX_OK;
+}
+
+// The AGB dust-yield table (config_helper.py:138-178: 11 degree-1 splines over (metallicity, mass)) for the step's
+// species pass: with it every step also leaves Z_i (drv:663 on the smoothed composition) and the yields of
+// config_helper.py:183-189 at (Z_i, m_i).  nspl == 0 switches it off.  Call after sphx_state_upload with f_un.
+extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                                  const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                                  const double* mu_specie, double solar_mass) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb before sphx_state_upload");
+    ctx->agb_on = false;
+    if (nspl == 0) return SPHX_OK;
+    if (ctx->s < 7 || ctx->s > AGB_MAX_SPEC || !ctx->st.fun.p)
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb: the state carries no composition (f_un) of >= 7 species");
+    if (!ntx || !nty || !tx || !ty || !coeffs || !mapto || !mu_specie)
+        return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: NULL argument");
+    if (nspl < 1 || nspl > AGB_MAX_SPL) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: %d splines", nspl);
+    if (!(divisor != 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: divisor is 0");
+    HIPCHK(hipSetDevice(ctx->device));
+    AgbTable& t = ctx->agb;
+    t.nspl = nspl; t.nspec = ctx->s;
+    size_t ntx_tot = 0, nty_tot = 0, nc_tot = 0;
+    for (int o = 0; o < nspl; ++o) {
+        if (ntx[o] < 4 || nty[o] < 4) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: spline %d has fewer than 4 knots", o);
+        if (mapto[o] < 0 || mapto[o] >= ctx->s) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: mapto[%d]=%d out of range", o, mapto[o]);
+        ntx_tot += ntx[o]; nty_tot += nty[o]; nc_tot += (size_t)(ntx[o] - 2) * (nty[o] - 2);
+    }
+    size_t ox = 0, oy = ntx_tot, oc = ntx_tot + nty_tot;
+    for (int o = 0; o < nspl; ++o) {
+        t.tx_off[o] = (int)ox; t.ty_off[o] = (int)oy; t.c_off[o] = (int)oc;
+        t.ntx[o] = ntx[o]; t.nty[o] = nty[o]; t.mapto[o] = mapto[o];
+        ox += ntx[o]; oy += nty[o]; oc += (size_t)(ntx[o] - 2) * (nty[o] - 2);
+    }
+    for (int s = 0; s < ctx->s; ++s) t.mu[s] = mu_specie[s];
+    t.divisor = divisor; t.solar = solar_mass;
+    SPHX_TRY(sphx_ensure(ctx, ctx->agb_knots, (ntx_tot + nty_tot + nc_tot) * sizeof(double)));
+    double* kd = ctx->agb_knots.as<double>();
+    HIPCHK(hipMemcpyAsync(kd, tx, ntx_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(kd + ntx_tot, ty, nty_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(kd + ntx_tot + nty_tot, coeffs, nc_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    t.knots = kd;
+    ctx->agb_on = true;
+    return SPHX_OK;
+}
+
+// F (S,n) species number densities of the last step (nsc:624-627), Z (n,), agb_dust (n,S) - caller order; any may be NULL
+__global__ __launch_bounds__(256) void scatter_species_major(int n, int S, const int* id, const double* in, double* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const size_t o = (size_t)id[t];
+    for (int s = 0; s < S; ++s) out[(size_t)s * n + o] = in[(size_t)s * n + t];
+}
+extern "C" int sphx_state_download_species(sphx_ctx* ctx, double* F, double* Z, double* agb_dust) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state || ctx->s < 1 || !ctx->st.fun.p || ctx->step_count < 1)
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_download_species: no species pass has run (state without f_un, "
+                                                 "or no step yet)");
+    if ((Z || agb_dust) && !ctx->agb_on) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_download_species: no AGB table set");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const int S = ctx->s;
+    const int* id = ctx->st.id.as<int>();
+    SPHX_TRY(sphx_ensure(ctx, ctx->out_a, (size_t)n * S * sizeof(double)));
+    double* stage = ctx->out_a.as<double>();
+    if (F) {
+        hipLaunchKernelGGL(scatter_species_major, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, S, id,
+                           ctx->F.as<double>(), stage);
+        SPHX_TRY(download(ctx, F, stage, (size_t)n * S * sizeof(double)));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (Z) {
+        SPHX_TRY(sphx_scatter_rows_by_id(ctx, n, 1, id, ctx->Zmet.as<double>(), stage));
+        SPHX_TRY(download(ctx, Z, stage, (size_t)n * sizeof(double)));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (agb_dust) {
+        SPHX_TRY(sphx_scatter_rows_by_id(ctx, n, S, id, ctx->agb_dust.as<double>(), stage));
+        SPHX_TRY(download(ctx, agb_dust, stage, (size_t)n * S * sizeof(double)));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return SPHX_OK;
 }
 

@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int id = a.id_src[p];
     a.id_dst[t] = id;
     a.inv[id] = t;
-    if (a.fun_src) {
-        for (int q = 0; q < a.s; ++q) a.fun_dst[(size_t)t * a.s + q] = a.fun_src[(size_t)p * a.s + q];
+    if (a.fun_src) {                       // rows of a.s doubles, a multiple of 16: aligned 16-B copies
+        const double2* src = reinterpret_cast<const double2*>(a.fun_src + (size_t)p * a.s);
+        double2* dst = reinterpret_cast<double2*>(a.fun_dst + (size_t)t * a.s);
+        for (int q = 0; q < a.s / 2; ++q) dst[q] = src[q];
     }
 }
 
@@ -61,7 +63,7 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
     DevBuf* dst[] = {&b.x, &b.y, &b.z, &b.vx, &b.vy, &b.vz, &b.ax, &b.ay, &b.az,
                      &b.m, &b.T, &b.mu, &b.gam, &b.E, &b.hprev, &b.ptype};
     GatherArgs g;
-    g.n = (int)n; g.narr = 16; g.s = ctx->s;
+    g.n = (int)n; g.narr = 16; g.s = ctx->sp;
     g.perm = ctx->perm.as<int>();
     for (int q = 0; q < 16; ++q) {
         SPHX_TRY(sphx_ensure(ctx, *dst[q], (size_t)n * sizeof(double)));
@@ -80,7 +82,7 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
     g.id_src = a.id.as<int>(); g.id_dst = b.id.as<int>(); g.inv = ctx->inv.as<int>();
     g.fun_src = nullptr; g.fun_dst = nullptr;
     if (ctx->s > 0 && a.fun.p) {
-        SPHX_TRY(sphx_ensure(ctx, b.fun, (size_t)n * ctx->s * sizeof(double)));
+        SPHX_TRY(sphx_ensure(ctx, b.fun, (size_t)n * ctx->sp * sizeof(double)));
         g.fun_src = a.fun.as<double>(); g.fun_dst = b.fun.as<double>();
     }
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g);

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include "../../include/sphx.h"
+#include "sphx_agb.h"
 
 #define SPHX_WAVE 64
 #define SPHX_W6_C 1.5666814710608448    /* 315 / (64 pi), nsc:588 */
@@ -85,6 +86,7 @@ struct sphx_ctx {
     // ---- working set (any particle order) ----
     int64_t n = 0, npad = 0;
     int k = 0, s = 0;
+    int sp = 0;                   // doubles per particle of the resident composition rows: s padded to whole 128-B lines
     DevBuf rec1, recv;            // RecA[n], RecB[n]
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
@@ -118,6 +120,10 @@ struct sphx_ctx {
     const int* qorder = nullptr;    // nullptr: identity
     DevBuf porder, mcount, mstart;
     bool use_blob = true;
+    // species pass inside the step (nsc:624-627) + per-particle metallicity + fused AGB yields (sphx_state_set_agb)
+    bool agb_on = false;
+    AgbTable agb;
+    DevBuf agb_knots, Zmet, agb_dust;
     // the fused loop's first pass (sphx_grid.hip grid_count_fused): clamp + box statistics + cell histogram in one kernel
     bool fuse_count = true;               // SPHX_FUSE_COUNT=0: the separate kernels
     double *clamp_vx = nullptr, *clamp_vy = nullptr, *clamp_vz = nullptr;   // set by the step: the grid build applies drv:233-238
@@ -281,6 +287,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k);
 int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double* ptype);
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F);
+int sphx_step_species(sphx_ctx* ctx, int64_t n, int k);
 int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmajor);
 
 // integrate / layout helpers (sphx_integrate.hip)

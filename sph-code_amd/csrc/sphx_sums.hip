@@ -500,3 +500,101 @@ int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun,
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
+
+
+// ---- the species pass of the STEP (nsc:624-627 on the step's own list) with the composition's consumers fused in ----
+// One thread per particle keeps all S species sums (the array-API kernel above splits them over blockIdx.y), so that
+// the epilogue can form, without another pass over memory:
+//   Z_i   = sum_{s >= 6} F[s,i] mu_s / sum_s F[s,i] mu_s      the metallicity expression of drv:663 on the SPH-smoothed
+//                                                             composition at the particle;
+//   agb_i = the AGB dust yields of config_helper.py:183-189 at (Z_i, m_i)        (BASELINE configs[4]: "metallicity
+//           lookup fused into the density pass"; the table lives in the context, sphx_state_set_agb).
+template <int SMAX>
+__global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int k, int S, int SP, const int* __restrict__ nbr,
+                                                           const RecA* __restrict__ rec, const double* __restrict__ fun,
+                                                           const int* __restrict__ qorder, const double* __restrict__ m,
+                                                           AgbTable agb, int agb_on, double* F, double* Zout,
+                                                           double* agb_out) {
+    const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;
+    int j0 = nbr[p];
+    if (j0 < 0) j0 = i;
+    const double xr = rec[j0].x, yr = rec[j0].y, zr = rec[j0].z;
+    double acc[SMAX];
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q) acc[q] = 0.0;
+    // four list positions at a time: indices, then records, then the composition rows, then the arithmetic
+    for (int kk0 = 0; kk0 < k; kk0 += 4) {
+        int jb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jb[u] = (kk0 + u < k) ? nbr[(size_t)(kk0 + u) * npad + p] : -1;
+        double wN[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = jb[u] < 0 ? i : jb[u];
+            const double* q = reinterpret_cast<const double*>(&rec[jj]);
+            const Q4 q0 = load4(q);
+            const double c1 = q[4], Nw = q[7];
+            const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
+            const double r = sqrt(dx * dx + dy * dy + dz * dz);
+            const double qj = q0.d - r * r;
+            double W = c1 * (qj * qj * qj);
+            W = (W < 0.0) ? 0.0 : W;
+            wN[u] = jb[u] < 0 ? 0.0 : Nw * W;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jb[u] < 0) continue;
+            // (rows are padded with zeros to SP doubles, whole 128-B lines: no bound test, 16-B loads)
+            const double2* f = reinterpret_cast<const double2*>(fun + (size_t)jb[u] * SP);
+#pragma unroll
+            for (int t = 0; t < SMAX / 2; ++t) {
+                if (2 * t < SP) {
+                    const double2 v = f[t];
+                    acc[2 * t] += wN[u] * v.x;
+                    acc[2 * t + 1] += wN[u] * v.y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t)
+        if (t < S) F[(size_t)t * n + i] = acc[t];
+    if (!agb_on) return;
+    double heavy = 0.0, all = 0.0;
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) {
+        if (t < S) {
+            const double w = acc[t] * agb.mu[t];
+            all += w;
+            if (t >= 6) heavy += w;
+        }
+    }
+    const double Z = heavy / all;                            // drv:663 (0/0 -> NaN for a particle without gas neighbours)
+    Zout[i] = Z;
+    double dust[AGB_MAX_SPEC];
+    agb_dust_yields(agb, m[i], Z, dust);
+    for (int t = 0; t < S; ++t) agb_out[(size_t)i * S + t] = dust[t];
+}
+
+int sphx_step_species(sphx_ctx* ctx, int64_t n, int k) {
+    const int S = ctx->s;
+    SPHX_TRY(sphx_ensure(ctx, ctx->F, (size_t)n * S * sizeof(double)));
+    if (ctx->agb_on) {
+        SPHX_TRY(sphx_ensure(ctx, ctx->Zmet, (size_t)n * sizeof(double)));
+        SPHX_TRY(sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double)));
+    }
+    if (S <= 16)       // the reference's 15 species: sums in 16 registers
+        hipLaunchKernelGGL(step_species_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           (int)sphx_pad64(n), k, S, ctx->sp, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), ctx->st.fun.as<double>(),
+                           ctx->qorder, ctx->st.m.as<double>(), ctx->agb, ctx->agb_on ? 1 : 0, ctx->F.as<double>(),
+                           ctx->Zmet.as<double>(), ctx->agb_dust.as<double>());
+    else
+        hipLaunchKernelGGL(step_species_kernel<SPHX_MAX_SPECIES>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           (int)sphx_pad64(n), k, S, ctx->sp, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), ctx->st.fun.as<double>(),
+                           ctx->qorder, ctx->st.m.as<double>(), ctx->agb, ctx->agb_on ? 1 : 0, ctx->F.as<double>(),
+                           ctx->Zmet.as<double>(), ctx->agb_dust.as<double>());
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}

@@ -168,5 +168,20 @@ def dusty_sphere(n, seed=12350, dust_frac=0.05, **kw):
     return _finish(s["points"], s["velocities"], mass, s["T"], ptype=ptype, f_un=f_un)
 
 
-WORKLOADS = {"dusty_sphere": dusty_sphere, "uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
+def two_phase(n, seed=12351, dust_frac=0.10, **kw):
+    """C5: the reference's own two-phase IC (drv:120-152) - gas particles and dust SPH particles (particle_type 2,
+    mass DUST_MASS, composition dust_base) thrown into the same uniform cube - with a tenth of the particles dust."""
+    kw.pop("light", None)
+    s = uniform_cube(n, seed=seed, **kw)
+    rs = np.random.RandomState(seed + 1)
+    dust = rs.permutation(n)[:int(round(dust_frac * n))]
+    ptype = np.zeros(n)
+    ptype[dust] = 2.
+    mass = s["mass"].copy()
+    mass[dust] = DUST_MASS
+    f_un = np.where((ptype == 2.)[:, None], F_DUST[None, :], F_GAS[None, :])
+    return _finish(s["points"], s["velocities"], mass, s["T"], ptype=ptype, f_un=f_un)
+
+
+WORKLOADS = {"two_phase": two_phase, "dusty_sphere": dusty_sphere, "uniform_sphere": uniform_sphere, "polytrope": polytrope_sphere, "sedov": sedov_sphere,
              "uniform_cube": uniform_cube}

@@ -16,7 +16,11 @@ from ._lib import dp, f64
 class Simulation:
     def __init__(self, state, n_neigh=40, dist=None, device=None, with_species=False, ctx=None,
                  incremental=False, with_drag=False, gravity=None, G=6.67430e-11, clip_grad=False,
-                 forms="hydro_update", d=None, gravity_order=2):
+                 forms="hydro_update", d=None, gravity_order=2, agb=None):
+        """with_species: carry f_un on the device; every step (hydro_update mode) then also forms the species number
+        densities F[s,i] of nsc:624-627 on its own neighbour list.  agb = (splines, mapto, divisor) as
+        sph_code_amd.agb.interpolate_amounts returns them: the same pass also leaves the per-particle metallicity
+        (the expression of code_running.py:663) and the AGB dust yields of config_helper.py:183-189 (download_species)."""
         self.ctx = ctx if ctx is not None else _lib.Context(device)
         self.ctx.set_incremental(incremental)
         self.k = int(n_neigh)
@@ -48,6 +52,22 @@ class Simulation:
             c.check(c.lib.sphx_state_set_gravity(c.h, 1 if gravity == "direct" else 2, float(G)))
             # tree: cells carry their second moments (order 2, ~0.1 % rms force error) or monopoles only (1, ~1 %)
             c.check(c.lib.sphx_set_gravity_order(c.h, int(gravity_order)))
+        self.n_species = 0 if fu is None else fu.shape[1]
+        if agb is not None:
+            if fu is None:
+                raise ValueError("agb needs with_species=True and a state with f_un")
+            from . import compat
+            splines, mapto, divisor = agb
+            i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+            ntx = i32([sp.get_knots()[0].size for sp in splines]); nty = i32([sp.get_knots()[1].size for sp in splines])
+            cat = lambda parts: np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in parts]))
+            tx = cat([sp.get_knots()[0] for sp in splines]); ty = cat([sp.get_knots()[1] for sp in splines])
+            cf = cat([sp.get_coeffs() for sp in splines]); mp = i32(mapto)
+            mu = np.ascontiguousarray(compat.mu_specie[:self.n_species], dtype=np.float64)
+            p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+            c.check(c.lib.sphx_state_set_agb(c.h, len(splines), p32(ntx), p32(nty), dp(tx), dp(ty), dp(cf), p32(mp),
+                                             float(divisor), dp(mu), compat.solar_mass))
+        self.has_agb = agb is not None
         if with_drag:
             # per-particle mean grain mass / cross-section as nsc.net_impulse forms them (nsc:720-726)
             from . import compat
@@ -75,6 +95,21 @@ class Simulation:
         out["dt"] = dt.value
         # P_i = n_i k_B T_i: the reference forms it and drops it (commented out at nsc:608); derived here
         out["pressure"] = out["num_densities"] * self.ctx.constants().k_B * out["T"]
+        return out
+
+    def download_species(self):
+        """-> dict: f_un_neighbor (S,N) as nsc.hydro_update returns it (nsc:671), and with an AGB table also
+        metallicity (N,) and agb_dust (N,S)."""
+        n, S = self.n, self.n_species
+        if S < 1:
+            raise RuntimeError("the simulation carries no composition (with_species=True and a state with f_un)")
+        out = dict(f_un_neighbor=np.empty((S, n)))
+        Z = A = None
+        if self.has_agb:
+            out["metallicity"] = Z = np.empty(n)
+            out["agb_dust"] = A = np.empty((n, S))
+        c = self.ctx
+        c.check(c.lib.sphx_state_download_species(c.h, dp(out["f_un_neighbor"]), dp(Z), dp(A)))
         return out
 
     # ---- snapshot / restart and per-step diagnostics (SURVEY 8f-4; the reference only wrote summary

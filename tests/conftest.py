@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:        # torch brings its own copy of the HIP runtime: in a process that uses both, it must be loaded BEFORE
+    import torch  # noqa: F401  libsphx.so pulls in the system one (else torch later finds "No HIP GPUs")
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

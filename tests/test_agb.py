@@ -107,3 +107,47 @@ def test_gpu_yields_bad_arguments(g):
         agb.calculate_interpolation([1.0], [0.01], splines, np.full(11, 99), 3, g["mu_specie"])
     with pytest.raises(ValueError):
         agb.calculate_interpolation([1.0, 2.0], [0.01], splines, g["mapto"], 3, g["mu_specie"])
+
+
+@pytest.mark.gpu
+def test_step_species_pass_with_fused_metallicity_and_agb_yields(g):
+    """BASELINE configs[4] in small: two-phase gas + dust (drv:120-152), every step also forms F[s,i] (nsc:624-627) on
+    its own neighbour list and, in the same pass, the per-particle metallicity (the expression of drv:663 on the
+    smoothed composition) and the AGB dust yields (config_helper.py:183-189) at (Z_i, m_i).  Oracle: a composition of
+    pinned pieces - hydro_update's F (golden vectors) -> Z -> agb_oracle.calculate_interpolation (reference outputs)."""
+    from oracle import sph_oracle as orc
+    from oracle import agb_oracle as ao
+    import sph_code_amd.ics as ics
+    import sph_code_amd.agb as agb
+    from sph_code_amd.sim import Simulation
+    n, K = 6000, 40
+    s = ics.two_phase(n)
+    assert np.isclose((s["particle_type"] == 2).mean(), 0.10, atol=0.002)
+    table = agb.splines_from_arrays(g["tx"], g["ty"], g["coeffs"], g["mapto"], float(g["divisor"]))
+    sim = Simulation(s, n_neigh=K, with_species=True, agb=table)
+    sim.step(1)
+    got = sim.download_species()
+    st = sim.download()
+    # the step's sums on the INITIAL state (clamped, searched) - the oracle on the same
+    p, v = orc.clamp_state(s["points"], s["velocities"])
+    nb, _, _, _, h = orc.neighbors(p, np.inf, K, eps=0.0)
+    np.testing.assert_allclose(st["sizes"], h, rtol=2e-15)
+    out = orc.hydro_update(nb, p, s["mass"], h, s["f_un"], s["particle_type"], s["T"], s["mu_array"], s["gamma_array"], v)
+    F = out[5]
+    np.testing.assert_allclose(got["f_un_neighbor"], F, rtol=1e-13, atol=0)
+    mu = orc.MU_SPECIE
+    with np.errstate(all="ignore"):
+        Z = (F[6:] * mu[6:, None]).sum(axis=0) / (F * mu[:, None]).sum(axis=0)
+    fin = np.isfinite(Z)
+    assert fin.mean() > 0.99
+    np.testing.assert_allclose(got["metallicity"][fin], Z[fin], rtol=1e-12, atol=1e-300)
+    assert (np.isnan(got["metallicity"]) == ~fin).all()
+    dust, _ = ao.calculate_interpolation(s["mass"][fin], got["metallicity"][fin], _splines(g), mu,
+                                         np.ones((fin.sum(), 15)), mapto=g["mapto"], divisor=float(g["divisor"]))
+    np.testing.assert_allclose(got["agb_dust"][fin], dust, rtol=1e-12, atol=0)
+    assert (got["agb_dust"][fin][:, [7, 8, 10, 11, 12, 13]] > 0).any()
+    # the array API's species sums agree with the step's (same list): bit for bit
+    import sph_code_amd.compat as nsc
+    idx, _, _, _, hh = nsc.neighbors(p, np.inf, K)
+    F2 = nsc.hydro_update(idx, p, s["mass"], hh, s["f_un"], s["particle_type"], s["T"], s["mu_array"], s["gamma_array"], v)[5]
+    assert np.array_equal(F2, got["f_un_neighbor"])
