@@ -677,8 +677,9 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
     ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
     if (getenv("SPHX_KG_DEBUG"))
-        fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu\n",
-                sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6]);
+        fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu | groups over the row cap %llu, over the pre-cull cap %llu\n",
+                sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6],
+                sc[SC_KGDBG + 7], sc[SC_KGDBG + 0]);
     return SPHX_OK;
 }
 

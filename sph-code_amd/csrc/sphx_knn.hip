@@ -18,6 +18,12 @@
 
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
+#ifndef KNN_LIST_BLOCKS
+#define KNN_LIST_BLOCKS 2048
+#endif
+#ifndef KNN_LIST_PPB
+#define KNN_LIST_PPB 16     // list mode: queries per workgroup and pass
+#endif
 #define KNN_MAX_TRIES 48
 #define KNN_FLAG_CAP 1024      // candidate slots per row chunk served by the flag lookup (else binary search)
 
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     do {
     // list mode: 4 queries per wave and pass instead of 16 - the list is short (a few per cent of the queries), so
     // the launch is bound by how long one wave takes, not by how many waves there are
-    constexpr int PPB = LIST ? 16 : KNN_PPB;
+    constexpr int PPB = LIST ? KNN_LIST_PPB : KNN_PPB;
     if (LIST && vblock * PPB >= total) break;
     const int base = vblock * PPB;
     // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
@@ -509,7 +515,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
         SPHX_TRY(sphx_knn_group(ctx, ga));
         a.qlist = flist; a.qcount = fcount;
-        int lblocks = blocks < 2048 ? blocks : 2048;
+        int lblocks = blocks < KNN_LIST_BLOCKS ? blocks : KNN_LIST_BLOCKS;
         if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
         else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
         HIPCHK(hipGetLastError());

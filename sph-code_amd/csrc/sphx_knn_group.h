@@ -3,9 +3,11 @@
 #include "sphx_internal.h"
 
 #ifndef KG_TCAP
-#define KG_TCAP 1920                     // candidates per group tile (11 bits of a key name the slot)
+#define KG_TCAP 1408                     // candidates per group tile after the cull (11 bits of a key name the slot)
 #endif
-#define KG_MAXROWS 512                   // rows of cells a group's tile may span (two per thread)
+#define KG_TPRE 3072                     // candidates of the rows of cells before the per-candidate cull (row ids: u16)
+#define KG_MAXROWS 512                   // NON-EMPTY rows of cells a group's tile may draw from
+#define KG_ROWS_ALL 8192                 // rows of cells (empty ones included) a group's box + radius may span
 static_assert(KG_TCAP <= 2048 && KG_TCAP % 64 == 0, "tile slots are named by 11 key bits");
 
 struct KnnGroupArgs {
@@ -25,6 +27,7 @@ struct KnnGroupArgs {
     int* fail_list;            // processing slots this kernel could not certify
     int* fail_count;
     u64* counters;
+    int exp_noamb;             // timing experiment (SPHX_KG_EXP_NOAMB): 0 in the product
     u64* prof;                 // diagnostics (nullptr in the product): per-section cycle sums
 };
 int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a);

@@ -112,12 +112,13 @@ template <int P> struct OemP {
 struct KgShared {
     double Ox, Oy, Oz, E;           // tile origin, largest |relative coordinate| (cell units)
     double cx0, cx1, cy0, cy1, cz0, cz1, R2, Rcov;   // box clamped into the grid, covered radius
+    float hx, hy, hz, rc2;          // the box's half extents and (covered radius)^2, cell units, rounded up
     int ry0, rz0, ysp, nrows, T, ok;
-    int wtot[4];
+    int wtot[4], wne[4];
 };
 
 #ifndef KG_MINWAVES
-#define KG_MINWAVES 4
+#define KG_MINWAVES 5
 #endif
 __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArgs a) {
     __shared__ f32x4 tile_xy[KG_TCAP / 2];
@@ -128,10 +129,9 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
 #define KG_OFF(t) ((((t) >> 1) << 2) | ((t) & 1))
     __shared__ unsigned short slist[64 * 64];       // [slot][query]: tile slots inside the query's radius;
                                                     // while staging: row of each slot (u8) + the rows' bases
-    static_assert(KG_TCAP * 2 + KG_MAXROWS * 4 <= 64 * 64 * 2, "slot->row ids + row bases share the list's memory");
-    static_assert(KG_MAXROWS == 512, "two rows per thread");
-    unsigned short* rowof = slist;                                               // KG_TCAP row ids
-    int* rowbase = reinterpret_cast<int*>(slist) + KG_TCAP / 2;                  // KG_MAXROWS ints
+    static_assert(KG_TPRE * 2 + KG_MAXROWS * 4 <= 64 * 64 * 2, "slot->row ids + row bases share the list's memory");
+        unsigned short* rowof = slist;                                               // KG_TPRE row ids
+    int* rowbase = reinterpret_cast<int*>(slist) + KG_TPRE / 2;                  // KG_MAXROWS ints
     __shared__ int cntq[64];
     __shared__ KgShared sh;
 
@@ -181,13 +181,18 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         if (lane == 0) {
             sh.Ox = 0.5 * (bx0 + bx1); sh.Oy = 0.5 * (by0 + by1); sh.Oz = 0.5 * (bz0 + bz1);
             sh.E = (fmax(fmax(bx1 - bx0, by1 - by0), bz1 - bz0) * 0.5 + Rcov) * g.inv_cell * 1.0001;
+            sh.hx = (float)((bx1 - bx0) * 0.5 * g.inv_cell) * 1.00001f + 1e-6f;
+            sh.hy = (float)((by1 - by0) * 0.5 * g.inv_cell) * 1.00001f + 1e-6f;
+            sh.hz = (float)((bz1 - bz0) * 0.5 * g.inv_cell) * 1.00001f + 1e-6f;
+            sh.rc2 = (float)((Rcov * g.inv_cell) * (Rcov * g.inv_cell)) * 1.0002f;
             sh.cx0 = fmin(fmax(bx0, g.xmin), gx1); sh.cx1 = fmin(fmax(bx1, g.xmin), gx1);
             sh.cy0 = cy0; sh.cy1 = cy1; sh.cz0 = cz0; sh.cz1 = cz1;
             sh.R2 = Rcov * Rcov; sh.Rcov = Rcov;
             sh.ry0 = ry0; sh.rz0 = rz0; sh.ysp = ry1 - ry0 + 1;
             sh.nrows = (ry1 - ry0 + 1) * (rz1 - rz0 + 1);
             sh.T = 0;
-            sh.ok = (okmask != 0ull && sh.nrows <= KG_MAXROWS) ? 1 : 0;
+            sh.ok = (okmask != 0ull && sh.nrows <= KG_ROWS_ALL) ? 1 : 0;
+            if (a.counters && okmask != 0ull && sh.nrows > KG_ROWS_ALL) atomicAdd(&a.counters[SC_KGDBG + 7], 1ull);   // diagnostics: groups over the row cap
         }
     }
     __syncthreads();
@@ -196,53 +201,73 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     const double Ox = sh.Ox, Oy = sh.Oy, Oz = sh.Oz;
     int T = 0;
     if (group_ok) {
-        // ---- two rows of cells per thread (rows 2 tid, 2 tid + 1): the chord of cells that can hold a particle
-        // within Rcov of the box ----
+        // ---- the rows of cells, 512 at a time (two per thread): the chord of cells that can hold a particle within Rcov
+        // of the box.  Only NON-EMPTY rows are kept (compact ids: the diffuse rim's groups span thousands of rows of
+        // which a few dozen hold anything); a slot remembers its row's id, a row its first particle. ----
         const double INF = INFINITY;
-        int s_row[2] = {0, 0}, cnt[2] = {0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = 2 * tid + u;
-            if (r < sh.nrows) {
-                const int ysp = sh.ysp;
-                const int rz = r / ysp, ry = r - rz * ysp;
-                const int cy = sh.ry0 + ry, cz = sh.rz0 + rz;
-                // distance from the (clamped) box to the row's (y,z) column of cells; boundary rows are open
-                const double ylo = (cy == 0) ? -INF : g.ymin + cy * g.cell, yhi = (cy == g.ny - 1) ? INF : g.ymin + (cy + 1) * g.cell;
-                const double zlo = (cz == 0) ? -INF : g.zmin + cz * g.cell, zhi = (cz == g.nz - 1) ? INF : g.zmin + (cz + 1) * g.cell;
-                const double dy = fmax(fmax(ylo - sh.cy1, sh.cy0 - yhi), 0.0) * 0.999999;      // (never over-estimated)
-                const double dz = fmax(fmax(zlo - sh.cz1, sh.cz0 - zhi), 0.0) * 0.999999;
-                const double rem = sh.R2 - (dy * dy + dz * dz);
-                if (rem >= 0.0) {
-                    const double xr = sqrt(rem) * 1.000001;
-                    const int x0 = cell_of_coord(sh.cx0 - xr, g.xmin, g.inv_cell, g.nx - 1);
-                    const int x1 = cell_of_coord(sh.cx1 + xr, g.xmin, g.inv_cell, g.nx - 1);
-                    const int row = (cz * g.ny + cy) * g.nx;
-                    s_row[u] = a.cell_start[row + x0];
-                    cnt[u] = a.cell_start[row + x1 + 1] - s_row[u];
-                }
-            }
-        }
-        const int incl = wave_scan_incl(cnt[0] + cnt[1]);
-        if (lane == 63) sh.wtot[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const int tw = sh.wtot[w]; if (w < wave) woff += tw; T += tw; }
-        if (T > KG_TCAP) group_ok = false;                           // (uniform over the workgroup)
-        if (group_ok) {
-            int off = woff + incl - (cnt[0] + cnt[1]);                // the first slot of the thread's rows in the tile
+        int nne = 0;                                                     // non-empty rows so far (uniform)
+        for (int r0 = 0; r0 < sh.nrows && group_ok; r0 += 512) {
+            int s_row[2] = {0, 0}, cnt[2] = {0, 0};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                rowbase[2 * tid + u] = s_row[u] - off;                // slot t of row r is particle rowbase[r] + t
-                for (int q = 0; q < cnt[u]; ++q) rowof[off + q] = (unsigned short)(2 * tid + u);
-                off += cnt[u];
+                const int r = r0 + 2 * tid + u;
+                if (r < sh.nrows) {
+                    const int ysp = sh.ysp;
+                    const int rz = r / ysp, ry = r - rz * ysp;
+                    const int cy = sh.ry0 + ry, cz = sh.rz0 + rz;
+                    // distance from the (clamped) box to the row's (y,z) column of cells; boundary rows are open
+                    const double ylo = (cy == 0) ? -INF : g.ymin + cy * g.cell, yhi = (cy == g.ny - 1) ? INF : g.ymin + (cy + 1) * g.cell;
+                    const double zlo = (cz == 0) ? -INF : g.zmin + cz * g.cell, zhi = (cz == g.nz - 1) ? INF : g.zmin + (cz + 1) * g.cell;
+                    const double dy = fmax(fmax(ylo - sh.cy1, sh.cy0 - yhi), 0.0) * 0.999999;      // (never over-estimated)
+                    const double dz = fmax(fmax(zlo - sh.cz1, sh.cz0 - zhi), 0.0) * 0.999999;
+                    const double rem = sh.R2 - (dy * dy + dz * dz);
+                    if (rem >= 0.0) {
+                        const double xr = sqrt(rem) * 1.000001;
+                        const int x0 = cell_of_coord(sh.cx0 - xr, g.xmin, g.inv_cell, g.nx - 1);
+                        const int x1 = cell_of_coord(sh.cx1 + xr, g.xmin, g.inv_cell, g.nx - 1);
+                        const int row = (cz * g.ny + cy) * g.nx;
+                        s_row[u] = a.cell_start[row + x0];
+                        cnt[u] = a.cell_start[row + x1 + 1] - s_row[u];
+                    }
+                }
             }
+            const int mycnt = cnt[0] + cnt[1], myne = (cnt[0] > 0 ? 1 : 0) + (cnt[1] > 0 ? 1 : 0);
+            const int incl = wave_scan_incl(mycnt), incn = wave_scan_incl(myne);
+            if (lane == 63) { sh.wtot[wave] = incl; sh.wne[wave] = incn; }
+            __syncthreads();
+            int woff = 0, wn = 0, totT = 0, totN = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int tw = sh.wtot[w], nw_ = sh.wne[w];
+                if (w < wave) { woff += tw; wn += nw_; }
+                totT += tw; totN += nw_;
+            }
+            if (T + totT > KG_TPRE || nne + totN > KG_MAXROWS) {          // (uniform over the workgroup)
+                group_ok = false;
+                if (a.counters && tid == 0) atomicAdd(&a.counters[SC_KGDBG + (T + totT > KG_TPRE ? 0 : 7)], 1ull);   // diagnostics
+            } else {
+                int off = T + woff + incl - mycnt;                         // the first slot of the thread's rows in the tile
+                int id = nne + wn + incn - myne;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (cnt[u] > 0) {
+                        rowbase[id] = s_row[u] - off;                      // slot t of row `id` is particle rowbase[id] + t
+                        for (int q = 0; q < cnt[u]; ++q) rowof[off + q] = (unsigned short)id;
+                        off += cnt[u];
+                        ++id;
+                    }
+                }
+            }
+            T += totT; nne += totN;
+            __syncthreads();
         }
         __syncthreads();
         KG_STAMP(1)
-        // ---- stage: one slot per thread and pass; two passes' loads in flight ----
+        // ---- stage: one candidate per thread and pass (two passes' loads in flight).  The rows hold whole cells; a
+        // candidate is kept only if it lies within Rcov of the group's box (the exact box + sphere region, not its cover
+        // by cells: a quarter fewer slots for phase A), the kept ones compacted per wave (ballot + one LDS add). ----
         if (group_ok) {
+            const float hx = sh.hx, hy = sh.hy, hz = sh.hz, rc2 = sh.rc2;
             for (int t0 = 0; t0 < T; t0 += 512) {
                 int pp[2];
 #pragma unroll
@@ -258,15 +283,31 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (pp[u] >= 0) {
-                        const int o = KG_OFF(t0 + 256 * u + tid);
-                        txy[o] = (float)((X[u] - Ox) * g.inv_cell);
-                        txy[o + 2] = (float)((Y[u] - Oy) * g.inv_cell);
-                        tzi[o] = (float)((Z[u] - Oz) * g.inv_cell);
+                    const float rx = (float)((X[u] - Ox) * g.inv_cell), ry = (float)((Y[u] - Oy) * g.inv_cell),
+                                rz = (float)((Z[u] - Oz) * g.inv_cell);
+                    const float ex = fmaxf(fabsf(rx) - hx, 0.0f), ey = fmaxf(fabsf(ry) - hy, 0.0f), ez = fmaxf(fabsf(rz) - hz, 0.0f);
+                    const bool keep = pp[u] >= 0 && fmaf(ez, ez, fmaf(ey, ey, ex * ex)) <= rc2;
+                    const u64 km = __builtin_amdgcn_ballot_w64(keep);
+                    int base = 0;
+                    if (km) {
+                        if (lane == 0) base = atomicAdd(&sh.T, __popcll(km));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    const int slot = base + lanes_below(km);
+                    if (keep && slot < KG_TCAP) {
+                        const int o = KG_OFF(slot);
+                        txy[o] = rx; txy[o + 2] = ry; tzi[o] = rz;
                         reinterpret_cast<int*>(tzi)[o + 2] = pp[u];
                     }
                 }
             }
+        }
+    }
+    __syncthreads();
+    if (group_ok) {
+        T = sh.T;                                                         // candidates kept
+        if (T > KG_TCAP) group_ok = false;
+        else {
             // pad the tile to whole mask words with records nobody accepts
             const int nwp = (T + 31) >> 5;
             if (tid < nwp * 32 - T) {
@@ -334,20 +375,38 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     }
     __syncthreads();
     KG_STAMP(3)
-    if (wave != 0) return;               // wave 0 finishes the group
-    const int cnt = cntq[lane];
-    if (ok && (cnt > 64 || cnt < K)) { ok = false; fail = true; why = cnt > 64 ? 4 : 5; }
-    const int maxcnt = (int)wmax((double)(ok ? cnt : 0));
+    // ---- the tail: wave w finishes queries 16 w .. 16 w + 15 with FOUR LANES PER QUERY ------------------------------
+    // (lane = 4 * local query + part).  The query's slot list is dealt cyclically over its four lanes (slot = part +
+    // 4 u: balanced by construction), each lane builds 16 keys, and the 64 keys of a query are ordered by a bitonic
+    // network whose element index is  e = 16 * part + u : the 18 stages with partner distance < 16 are compare-
+    // exchanges between a lane's own registers, the 3 stages at distance 16 / 32 exchange with lane ^ 1 / lane ^ 2 of
+    // the quad through DPP.  All four waves work to the end (the first version left the tail to wave 0 alone: 46 % of
+    // a group's lifetime with one wave in four busy).
+    const int ql = lane >> 2, part = lane & 3;
+    const int src = wave * 16 + ql;                        // the lane that holds this query's data in every wave
+    const bool q_ok0 = __shfl((int)ok, src, 64) != 0;
+    const bool q_isq = __shfl((int)is_query, src, 64) != 0;
+    const bool q_fail0 = __shfl((int)fail, src, 64) != 0;
+    int q_why = __shfl(why, src, 64);
+    const float tqx = __shfl(fqx, src, 64), tqy = __shfl(fqy, src, 64), tqz = __shfl(fqz, src, 64);
+    const double Rc_q = __shfl(Rc, src, 64);
+    const double tol_q = __shfl(tol_rel, src, 64);
+    const int qs_q = __shfl(qs, src, 64), qid_q = __shfl(qid, src, 64);
+    const int pq = xcd_block(blockIdx.x, gridDim.x) * 64 + src;             // the query's processing slot = list column
+    const int cnt = cntq[src];
+    bool okq = q_ok0, failq = q_fail0;
+    if (okq && (cnt > 64 || cnt < K)) { okq = false; failq = true; q_why = cnt > 64 ? 4 : 5; }
+    const int maxcnt = (int)wmax((double)(okq ? cnt : 0));
 
-    // ---- phase B: slot lists -> keys in registers ----
-    u32 key[64];
-    const float kscale = ok ? (float)(2097152.0 / (Rc * Rc * 1.0002)) : 0.0f;
+    // ---- phase B: the lane's 16 list entries -> keys ----
+    u32 key[16];
+    const float kscale = okq ? (float)(2097152.0 / (Rc_q * Rc_q * 1.0002)) : 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {                       // 8 slots at a time: list reads, then tile reads, then arithmetic
-        if (c * 8 < maxcnt) {
+    for (int c = 0; c < 2; ++c) {                       // 8 entries at a time: list reads, then tile reads, then arithmetic
+        if (c * 32 < maxcnt) {
             int tt[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tt[u] = slist[(c * 8 + u) * 64 + lane];
+            for (int u = 0; u < 8; ++u) tt[u] = slist[(part + 4 * (c * 8 + u)) * 64 + src];
             float cx[8], cy[8], cz[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -356,13 +415,13 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float dx = cx[u] - fqx, dy = cy[u] - fqy, dz = cz[u] - fqz;
+                const float dx = cx[u] - tqx, dy = cy[u] - tqy, dz = cz[u] - tqz;
                 float d2 = dx * dx;
                 d2 = fmaf(dy, dy, d2);
                 d2 = fmaf(dz, dz, d2);
                 u32 qd = (u32)(d2 * kscale);
                 qd = qd > 2097151u ? 2097151u : qd;
-                key[c * 8 + u] = (ok && c * 8 + u < cnt) ? ((qd << 11) | (u32)tt[u]) : 0xFFFFFFFFu;
+                key[c * 8 + u] = (okq && part + 4 * (c * 8 + u) < cnt) ? ((qd << 11) | (u32)tt[u]) : 0xFFFFFFFFu;
             }
         } else {
 #pragma unroll
@@ -370,63 +429,140 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         }
     }
     KG_STAMP(4)
-    // ---- order the 64 registers ----
-    OemP<1>::run(key);
+    // ---- order: bitonic network on e = 16 * part + u (ascending) ----
+    // for k = 2 .. 64, j = k/2 .. 1: compare-exchange (e, e | j), ascending where (e & k) == 0.  j < 16: both elements in
+    // one lane; j = 16 / 32: partner in lane ^ 1 / lane ^ 2 (DPP quad_perm).  The direction is a compile-time property
+    // of the register pair for k <= 8; for k = 16 it depends on part & 1, for k = 32 on part & 2: lanes that must sort
+    // descending carry COMPLEMENTED keys through that phase (descending on x = ascending on ~x), so every
+    // compare-exchange is the same min/max pair in all lanes.
+    {
+#define KG_CEA(a_, b_) { const u32 lo_ = min(key[a_], key[b_]); const u32 hi_ = max(key[a_], key[b_]); key[a_] = lo_; key[b_] = hi_; }
+#define KG_CED(a_, b_) { const u32 lo_ = min(key[a_], key[b_]); const u32 hi_ = max(key[a_], key[b_]); key[a_] = hi_; key[b_] = lo_; }
+#pragma unroll
+        for (int k2 = 2; k2 <= 8; k2 <<= 1) {
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if ((u & j) == 0) {
+                        if ((u & k2) == 0) KG_CEA(u, u | j) else KG_CED(u, u | j)
+                    }
+            }
+        }
+        const u32 c16 = (part & 1) ? 0xFFFFFFFFu : 0u;         // k = 16: odd parts sort descending
+        const u32 c32 = (part & 2) ? 0xFFFFFFFFu : 0u;         // k = 32: parts 2, 3 merge descending
+#pragma unroll
+        for (int u = 0; u < 16; ++u) key[u] ^= c16;
+#pragma unroll
+        for (int j = 8; j > 0; j >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((u & j) == 0) KG_CEA(u, u | j)
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) key[u] ^= (c16 ^ c32);    // out of the k = 16 phase, into the k = 32 phase
+        // k = 32, j = 16: lane ^ 1; the lower lane of the pair (part & 1 == 0) keeps the minimum
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const u32 pk = xchg32<1>(key[u]);
+            const u32 lo_ = min(key[u], pk), hi_ = max(key[u], pk);
+            key[u] = select_const<0x5555555555555555ull>(lo_, hi_);
+        }
+#pragma unroll
+        for (int j = 8; j > 0; j >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((u & j) == 0) KG_CEA(u, u | j)
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) key[u] ^= c32;            // true keys again; k = 64 is ascending everywhere
+        // k = 64, j = 32: lane ^ 2 (lower: part & 2 == 0), j = 16: lane ^ 1
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const u32 pk = xchg32<2>(key[u]);
+            const u32 lo_ = min(key[u], pk), hi_ = max(key[u], pk);
+            key[u] = select_const<0x3333333333333333ull>(lo_, hi_);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const u32 pk = xchg32<1>(key[u]);
+            const u32 lo_ = min(key[u], pk), hi_ = max(key[u], pk);
+            key[u] = select_const<0x5555555555555555ull>(lo_, hi_);
+        }
+#pragma unroll
+        for (int j = 8; j > 0; j >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if ((u & j) == 0) KG_CEA(u, u | j)
+        }
+    }
+    // rank r of a query now sits in lane part = r / 16, register r % 16
 
     // ---- certify: consecutive keys among the first K+1 further apart than twice the error bound ----
     {
         // bins of 2^-21 R^2(1.0002): each d2 within tol of the truth, each key a floor of (d2 x a rounded scale): two keys
         // further apart than 2 tol + 2 bins are in their true order
-        const u32 win = ok ? (u32)(2.0 * tol_rel * 2097152.0) + 3u : 0u;
+        const u32 win = okq ? (u32)(2.0 * tol_q * 2097152.0) + 3u : 0u;
+        const u32 nextfirst = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key[0], 0x39, 0xF, 0xF, false);  // quad_perm [1,2,3,0]: lane + 1
         bool amb = false;
 #pragma unroll
-        for (int r = 0; r < 63; ++r)
-            if (r < K && key[r + 1] != 0xFFFFFFFFu && (key[r + 1] >> 11) - (key[r] >> 11) <= win) amb = true;
-        if (ok && amb) { ok = false; fail = true; why = 6; }
+        for (int u = 0; u < 16; ++u) {
+            const int r = part * 16 + u;
+            const u32 nxt = (u < 15) ? key[(u + 1) & 15] : (part < 3 ? nextfirst : 0xFFFFFFFFu);
+            if (r < K && nxt != 0xFFFFFFFFu && (nxt >> 11) - (key[u] >> 11) <= win) amb = true;
+        }
+        // any of the query's four lanes
+        int am = amb ? 1 : 0;
+        am |= __builtin_amdgcn_update_dpp(0, am, 0xB1, 0xF, 0xF, true);
+        am |= __builtin_amdgcn_update_dpp(0, am, 0x4E, 0xF, 0xF, true);
+        if (okq && am && !a.exp_noamb) { okq = false; failq = true; q_why = 6; }
     }
     KG_STAMP(5)
-    // ---- outputs: 8 list positions at a time (index reads from the tile batched, then the row stores) ----
+    // ---- outputs: rank r = 16 part + u ----
     {
-        int lastidx = -1;
         const int* tidx = reinterpret_cast<const int*>(tzi);
-        const bool wr = p < a.npad && (ok || !is_query);   // failed queries are written by the list-mode launch that
+        const bool wr = pq < a.npad && (okq || !q_isq);    // failed queries are written by the list-mode launch that
                                                             // follows; non-queries (ghosts, padding) get -1
+        int idx[16];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c * 8 < K) {
-                int idx[8];
+        for (int u = 0; u < 16; ++u) idx[u] = (part * 16 + u < K) ? tidx[KG_OFF(okq ? (key[u] & 2047u) : 0u) + 2] : -1;
+        // the K-th neighbour's exact distance: its loads go out before the row stores
+        const int rl = K - 1;
+        int lastidx = -1;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) idx[u] = tidx[KG_OFF(ok ? (key[c * 8 + u] & 2047u) : 0u) + 2];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = c * 8 + u;
-                    const int v = ok ? idx[u] : -1;
-                    if (r == K - 1) lastidx = v;
-                    if (r < K && wr) a.nbr[(size_t)r * a.npad + p] = v;
-                }
-            }
+        for (int u = 0; u < 16; ++u) if ((rl & 15) == u) lastidx = idx[u];
+        const bool mine = okq && part == (rl >> 4);
+        double lx = 0.0, ly = 0.0, lz = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+        if (mine) {
+            lx = a.x[lastidx]; ly = a.y[lastidx]; lz = a.z[lastidx];
+            sx = a.x[qs_q]; sy = a.y[qs_q]; sz = a.z[qs_q];
         }
-        if (ok) {
-            const double d2 = dist2_nofma(a.x[lastidx] - qx, a.y[lastidx] - qy, a.z[lastidx] - qz);
-            const double hval = sqrt(d2);
-            if (a.h_by_id) a.h_by_id[qid] = hval; else a.h_sorted[qs] = hval;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = part * 16 + u;
+            if (r < K && wr) a.nbr[(size_t)r * a.npad + pq] = okq ? idx[u] : -1;
+        }
+        if (mine) {
+            const double hval = sqrt(dist2_nofma(lx - sx, ly - sy, lz - sz));
+            if (a.h_by_id) a.h_by_id[qid_q] = hval; else a.h_sorted[qs_q] = hval;
         }
     }
     KG_STAMP(6)
-    const u64 failmask = __builtin_amdgcn_ballot_w64(fail);
+    const bool rep = part == 0;                            // one lane speaks for the query
+    const u64 failmask = __builtin_amdgcn_ballot_w64(failq && rep);
     if (failmask) {
         int base = 0;
         if (lane == 0) base = atomicAdd(a.fail_count, __popcll(failmask));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (fail) a.fail_list[base + lanes_below(failmask)] = p;
+        if (failq && rep) a.fail_list[base + lanes_below(failmask)] = pq;
         if (a.counters) {
             for (int wq = 1; wq <= 6; ++wq) {
-                const u64 mk = __builtin_amdgcn_ballot_w64(fail && why == wq);
+                const u64 mk = __builtin_amdgcn_ballot_w64(failq && rep && q_why == wq);
                 if (lane == 0 && mk) atomicAdd(&a.counters[SC_KGDBG + wq], (u64)__popcll(mk));
             }
         }
     }
-    if (lane == 0 && a.counters) atomicAdd(&a.counters[SC_CAND], (u64)T * (u64)__popcll(okmask));
+    if (tid == 0 && a.counters) atomicAdd(&a.counters[SC_CAND], (u64)T * (u64)__popcll(okmask));
     KG_STAMP(7)
 }
 
@@ -434,6 +570,8 @@ int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a0) {
     KnnGroupArgs a = a0;
     const int blocks = a.npad / 64;
     a.prof = nullptr;
+    static const bool noamb = getenv("SPHX_KG_EXP_NOAMB") != nullptr;     // timing experiment only: near ties NOT handed on (wrong results)
+    a.exp_noamb = noamb ? 1 : 0;
     static const bool prof = getenv("SPHX_KG_PROF") != nullptr;
     if (prof) {           // diagnostic: per-section shader cycles of one launch (summed over the waves' lane 0)
         SPHX_TRY(sphx_ensure(ctx, ctx->scal_tmp, 4096));
