@@ -779,3 +779,37 @@ def test_cloud_at_rest_takes_the_max_age_step(nsc):
         sim.first = False
         sim.step(1)
         assert sim.download()["dt"] == orc.MAX_AGE / 100., kw
+
+
+@pytest.mark.parametrize("workload,n,K,steps,kw", [
+    ("polytrope", 60000, 40, 6, {}), ("sedov", 30000, 40, 6, {}), ("uniform_cube", 30000, 16, 6, {}),
+    ("dusty_sphere", 20000, 64, 4, {}), ("uniform_sphere", 20000, 1, 3, {}),
+    ("uniform_cube", 40000, 40, 6, dict(forms="loop", d=1.25e6 * 149597870700.0))])
+def test_grouped_search_equals_general_search(workload, n, K, steps, kw, monkeypatch):
+    """The hinted searches of the step loop run the lane-per-query grouped kernel (fp32 distances, order certified
+    against a rigorous error bound, everything uncertain handed to the general kernel).  Switched off
+    (SPHX_KNN_GROUP=0: the wave-per-query kernel alone, exact fp64) the trajectory must be the same BIT FOR BIT - also
+    with Morton instead of Hilbert blobs (other groups, other tiles), through a blast (Courant-limited step: under the
+    reference's dt the blast reaches inf within 3 steps, where crowded boundary cells keep their arrival order and
+    even two runs of ONE build differ), through the reference scheme's divergence on the uniform cube (max |v| 4e52 m/s,
+    escapers clamped into boundary cells), with K = 1 and K = 64 (every list exactly full), and in loop-form mode."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    s0 = ics.WORKLOADS[workload](n)
+    fixed_dt = ics.cfl_dt(s0, K) if workload == "sedov" else 0.0
+    res, fb = {}, {}
+    for name, env in (("grouped", {}), ("general", {"SPHX_KNN_GROUP": "0"}), ("grouped_morton", {"SPHX_BLOB_CURVE": "1"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        sim = Simulation(s0, n_neigh=K, **kw)
+        sim.step(steps, fixed_dt=fixed_dt)
+        res[name] = sim.download()
+        fb[name] = sim.stats()["fallback_queries"]
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert fb["general"] == 0
+    if workload == "polytrope":
+        assert 0 < fb["grouped"] < 0.1 * n          # the grouped kernel really did certify nearly all of them
+    for name in ("general", "grouped_morton"):
+        for key in ("points", "velocities", "E_internal", "T", "sizes", "densities", "total_accel"):
+            assert np.array_equal(res["grouped"][key], res[name][key], equal_nan=True), (name, key)
