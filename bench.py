@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--species", action="store_true",
                     help="carry f_un and run the species pass (nsc:624-627) in every step, with the per-particle "
                          "metallicity and the AGB dust yields fused in (BASELINE configs[4]; 1488-B model)")
+    ap.add_argument("--drag", action="store_true", help="gas-dust drag in the step (nsc.net_impulse, drv:455,462-463,473)")
     ap.add_argument("--gravity", default=None, choices=["direct", "tree"],
                     help="self-gravity in the timed step (off in the BASELINE metric; DESIGN 5.7)")
     args = ap.parse_args()
@@ -146,7 +147,7 @@ def main():
         if state.get("f_un") is None:
             raise SystemExit("--species needs a workload that carries f_un (two_phase, dusty_sphere)")
     sim = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad,
-                     forms=args.forms, d=d_loop, with_species=args.species, agb=agb_table)
+                     forms=args.forms, d=d_loop, with_species=args.species, agb=agb_table, with_drag=args.drag)
     fixed_dt = ics.cfl_dt(state, args.k) if args.dt == "cfl" else 0.0
     sim.step(args.warmup, fixed_dt=fixed_dt)
     sim.reset_stats()
@@ -175,7 +176,7 @@ def main():
                                (args.workload, args.n, args.k),
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
                    "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale,
-                   "forms": args.forms, "species_pass": bool(args.species),
+                   "forms": args.forms, "species_pass": bool(args.species), "drag": bool(args.drag),
                    "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)"},
         # the reference's scheme can diverge: evidence that the timed window was a sane flow
         "state_check": {"finite": sane, "max_speed_m_s": vmax,

@@ -363,6 +363,23 @@ int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* pos, double*
                             const double* ptype, const double* delp, const double* rho, const double* av_accel,
                             const double* av_heat, const double* red2, int first, double fixed_dt, double dt,
                             double* dt_out);
+/* Gas-dust drag (nsc:719-742) in the decomposed step: after sphx_dev_prep; mass, ptype, mean_grain_mass, mean_cross
+ * (n_total,) ghosts included -> drag_on (n_total,3; owned rows: the sum over each owned particle's dust neighbours) and
+ * drag_reaction (n_total,3; EVERY row: the scatter-added reaction nsc:741 - the ghosts' rows are what their owners still
+ * have to add: the driver sends them back, the reverse halo).  sphx_dev_set_drag_terms hands the completed terms
+ * ((n_owned,...) arrays) to the NEXT sphx_dev_integrate / _auto / _loop call: drv:462-463,473.                        */
+int sphx_dev_drag(sphx_ctx* ctx, const double* mass, const double* ptype, const double* mean_grain_mass,
+                  const double* mean_cross, double* drag_on, double* drag_reaction);
+int sphx_dev_set_drag_terms(sphx_ctx* ctx, const double* drag_on, const double* drag_reaction, const double* rho,
+                            const double* rho_dust);
+/* Species pass (nsc:624-627) of the decomposed step: after sphx_dev_prep; f_un (n_total,nspecies), mass (n_total,) ghosts
+ * included -> F (nspecies,n_total); with a table set (sphx_dev_set_agb, arguments as sphx_state_set_agb) also Z (n_total,)
+ * and agb_dust (n_total,nspecies) as sphx_state_download_species defines them.  Owned entries written.                  */
+int sphx_dev_set_agb(sphx_ctx* ctx, int nspecies, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                     const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                     const double* mu_specie, double solar_mass);
+int sphx_dev_species(sphx_ctx* ctx, int nspecies, const double* f_un, const double* mass, double* F, double* Z,
+                     double* agb_dust);
 /* multigpu.py DistributedSim._replan: w_i = max((halo_scale + skin_frac) h_i, halo_scale h_i + |v_i| dt_last), the
  * reach an owned particle claims (h, w (n), vel (n,3): device).                                          */
 int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,

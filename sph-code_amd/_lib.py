@@ -93,6 +93,11 @@ SIGNATURES = {
     "sphx_dev_reach": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
     "sphx_dev_step_scalars": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "sphx_dev_integrate": (C.c_int, [_P, C.c_int64] + [_P] * 12 + [C.c_double]),
+    "sphx_dev_drag": (C.c_int, [_P] + [_P] * 6),
+    "sphx_dev_set_drag_terms": (C.c_int, [_P] + [_P] * 4),
+    "sphx_dev_set_agb": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D, _D, _D,
+                                   C.POINTER(C.c_int32), C.c_double, _D, C.c_double]),
+    "sphx_dev_species": (C.c_int, [_P, C.c_int] + [_P] * 5),
     "sphx_dev_loop_prep": (C.c_int, [_P] + [_P] * 8 + [C.c_double]),
     "sphx_dev_loop_pass1": (C.c_int, [_P] + [_P] * 5),
     "sphx_dev_loop_pass2": (C.c_int, [_P] + [_P] * 4),

@@ -720,29 +720,23 @@ extern "C" int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, doub
     return SPHX_OK;
 }
 
-// The AGB dust-yield table (config_helper.py:138-178: 11 degree-1 splines over (metallicity, mass)) for the step's
-// species pass: with it every step also leaves Z_i (drv:663 on the smoothed composition) and the yields of
-// config_helper.py:183-189 at (Z_i, m_i).  nspl == 0 switches it off.  Call after sphx_state_upload with f_un.
-extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
-                                  const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
-                                  const double* mu_specie, double solar_mass) {
-    if (!ctx) return SPHX_E_ARG;
-    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb before sphx_state_upload");
+// The AGB dust-yield table (config_helper.py:138-178: 11 degree-1 splines over (metallicity, mass)) into the context
+int sphx_agb_table_set(sphx_ctx* ctx, int S, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx, const double* ty,
+                       const double* coeffs, const int32_t* mapto, double divisor, const double* mu_specie, double solar_mass) {
     ctx->agb_on = false;
     if (nspl == 0) return SPHX_OK;
-    if (ctx->s < 7 || ctx->s > AGB_MAX_SPEC || !ctx->st.fun.p)
-        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb: the state carries no composition (f_un) of >= 7 species");
+    if (S < 7 || S > AGB_MAX_SPEC) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: %d species (7..%d)", S, AGB_MAX_SPEC);
     if (!ntx || !nty || !tx || !ty || !coeffs || !mapto || !mu_specie)
-        return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: NULL argument");
-    if (nspl < 1 || nspl > AGB_MAX_SPL) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: %d splines", nspl);
-    if (!(divisor != 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: divisor is 0");
+        return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: NULL argument");
+    if (nspl < 1 || nspl > AGB_MAX_SPL) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: %d splines", nspl);
+    if (!(divisor != 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: divisor is 0");
     HIPCHK(hipSetDevice(ctx->device));
     AgbTable& t = ctx->agb;
-    t.nspl = nspl; t.nspec = ctx->s;
+    t.nspl = nspl; t.nspec = S;
     size_t ntx_tot = 0, nty_tot = 0, nc_tot = 0;
     for (int o = 0; o < nspl; ++o) {
-        if (ntx[o] < 4 || nty[o] < 4) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: spline %d has fewer than 4 knots", o);
-        if (mapto[o] < 0 || mapto[o] >= ctx->s) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_state_set_agb: mapto[%d]=%d out of range", o, mapto[o]);
+        if (ntx[o] < 4 || nty[o] < 4) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: spline %d has fewer than 4 knots", o);
+        if (mapto[o] < 0 || mapto[o] >= S) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: mapto[%d]=%d out of range", o, mapto[o]);
         ntx_tot += ntx[o]; nty_tot += nty[o]; nc_tot += (size_t)(ntx[o] - 2) * (nty[o] - 2);
     }
     size_t ox = 0, oy = ntx_tot, oc = ntx_tot + nty_tot;
@@ -751,7 +745,7 @@ extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, c
         t.ntx[o] = ntx[o]; t.nty[o] = nty[o]; t.mapto[o] = mapto[o];
         ox += ntx[o]; oy += nty[o]; oc += (size_t)(ntx[o] - 2) * (nty[o] - 2);
     }
-    for (int s = 0; s < ctx->s; ++s) t.mu[s] = mu_specie[s];
+    for (int s = 0; s < S; ++s) t.mu[s] = mu_specie[s];
     t.divisor = divisor; t.solar = solar_mass;
     SPHX_TRY(sphx_ensure(ctx, ctx->agb_knots, (ntx_tot + nty_tot + nc_tot) * sizeof(double)));
     double* kd = ctx->agb_knots.as<double>();
@@ -762,6 +756,20 @@ extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, c
     t.knots = kd;
     ctx->agb_on = true;
     return SPHX_OK;
+}
+
+// ... for the step's species pass: with it every step also leaves Z_i (drv:663 on the smoothed composition) and the
+// yields of config_helper.py:183-189 at (Z_i, m_i).  nspl == 0 switches it off.  Call after sphx_state_upload with f_un.
+extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                                  const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                                  const double* mu_specie, double solar_mass) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb before sphx_state_upload");
+    ctx->agb_on = false;
+    if (nspl == 0) return SPHX_OK;
+    if (ctx->s < 7 || !ctx->st.fun.p)
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb: the state carries no composition (f_un) of >= 7 species");
+    return sphx_agb_table_set(ctx, ctx->s, nspl, ntx, nty, tx, ty, coeffs, mapto, divisor, mu_specie, solar_mass);
 }
 
 // F (S,n) species number densities of the last step (nsc:624-627), Z (n,), agb_dust (n,S) - caller order; any may be NULL

@@ -213,6 +213,7 @@ struct DevIntegArgs {
     double *pos, *vel, *acc, *E, *T;
     const double *m, *mu, *gam, *ptype, *ha, *va, *vh;
     const double *G, *rho;        // loop-form mode (G != nullptr): ha unused; pressure = G / rho [gas], visc = va (drv:460,473)
+    const double *drag_on, *drag_re, *drho, *drhod;   // gas-dust drag (drv:462-463,473); drag_on == nullptr: none
     double dt, m_h, kB, lim;
     // device-side verdict and dt (sphx_dev_integrate_auto): red2 = {halo too thin?, -min crossing time}
     const double* red2;
@@ -247,6 +248,10 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
             pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
             vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
         }
+        if (a.drag_on) {                                      // drv:462-463,473
+            const double dg = nan_to_num_v(a.drag_on[3 * (size_t)i + c] * a.drhod[i] / a.drho[i] * g);
+            vis[c] = dg + nan_to_num_v(a.drag_re[3 * (size_t)i + c]) + vis[c];
+        }
     }
     double x[3], old[3], tot[3];
 #pragma unroll
@@ -262,6 +267,11 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     sphx_energy_update(dt, a.vh[i], a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
     a.E[i] = E;
     a.T[i] = T;
+}
+// the drag terms handed over by sphx_dev_set_drag_terms are consumed by the next update
+static void take_drag_terms(sphx_ctx* ctx, DevIntegArgs& a) {
+    a.drag_on = ctx->dev_drag_on; a.drag_re = ctx->dev_drag_re; a.drho = ctx->dev_drag_rho; a.drhod = ctx->dev_drag_rhod;
+    ctx->dev_drag_on = ctx->dev_drag_re = ctx->dev_drag_rho = ctx->dev_drag_rhod = nullptr;
 }
 // drv:233-238 on (n,3) arrays
 __global__ __launch_bounds__(256) void dev_clamp_kernel(int n3, double lim, double* pos, double* vel) {
@@ -297,6 +307,7 @@ extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, d
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
     a.G = nullptr; a.rho = nullptr;
+    take_drag_terms(ctx, a);
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
@@ -324,6 +335,7 @@ extern "C" int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* p
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = hydro_accel; a.va = visc_accel; a.vh = visc_heat;
     a.G = nullptr; a.rho = nullptr;
+    take_drag_terms(ctx, a);
     a.dt = 0.0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
@@ -351,10 +363,125 @@ extern "C" int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* p
     a.m = mass; a.mu = mu; a.gam = gamma; a.ptype = ptype;
     a.ha = nullptr; a.va = av_accel; a.vh = av_heat;
     a.G = delp; a.rho = rho;
+    take_drag_terms(ctx, a);
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// ---- gas-dust drag (nsc:719-742) on owned + ghost arrays --------------------------------------------------------------
+// sorted[s] = caller[perm[s]] for four arrays at once
+__global__ __launch_bounds__(256) void dev_gather4_kernel(int n, const int* perm, const double* a0, const double* a1,
+                                                          const double* a2, const double* a3, double* d0, double* d1, double* d2,
+                                                          double* d3) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int c = perm[s];
+    d0[s] = a0[c]; d1[s] = a1[c]; d2[s] = a2[c]; d3[s] = a3[c];
+}
+// caller[perm[s], :] = sorted[s, :] for the first n_keep caller indices (w doubles per particle)
+__global__ __launch_bounds__(256) void dev_scatter_rows_kernel(int n, const int* perm, int n_keep, int w, const double* src,
+                                                               double* dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int c = perm[s];
+    if (c >= n_keep) return;
+    for (int q = 0; q < w; ++q) dst[(size_t)c * w + q] = src[(size_t)s * w + q];
+}
+// after sphx_dev_prep (records with the complete h): drag of the dust neighbours onto each OWNED particle -> drag_on
+// (n_total,3, owned rows written), and the scatter-added reaction onto the neighbours -> drag_reaction (n_total,3, every
+// row: the ghosts' rows are what their owners must still add - the driver's reverse halo).  mass, ptype,
+// mean_grain_mass, mean_cross: (n_total,) caller order, ghosts included.
+extern "C" int sphx_dev_drag(sphx_ctx* ctx, const double* mass, const double* ptype, const double* mean_grain_mass,
+                             const double* mean_cross, double* drag_on, double* drag_reaction) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(mass); NEED(ptype); NEED(mean_grain_mass); NEED(mean_cross); NEED(drag_on); NEED(drag_reaction);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_drag before sphx_dev_search");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    StateArrays& st = ctx->alt;
+    DevBuf* bufs[] = {&st.m, &st.ptype, &st.mgm, &st.mcs};
+    for (DevBuf* b : bufs) SPHX_TRY(sphx_ensure(ctx, *b, (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(dev_gather4_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, mass, ptype,
+                       mean_grain_mass, mean_cross, st.m.as<double>(), st.ptype.as<double>(), st.mgm.as<double>(),
+                       st.mcs.as<double>());
+    SPHX_TRY(sphx_pass_drag(ctx, n, ctx->k, st.m.as<double>(), st.ptype.as<double>(), st.mgm.as<double>(), st.mcs.as<double>()));
+    hipLaunchKernelGGL(dev_scatter_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive, 3,
+                       ctx->drag_on.as<double>(), drag_on);
+    hipLaunchKernelGGL(dev_scatter_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, (int)n, 3,
+                       ctx->drag_re.as<double>(), drag_reaction);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+// drv:462-463,473 for the NEXT sphx_dev_integrate / _auto / _loop call: visc += drag_on rho_dust / rho [gas] + drag_reaction
+// (all (n_owned, ...) device arrays, the reaction complete: own scatter + what the peers sent back)
+extern "C" int sphx_dev_set_drag_terms(sphx_ctx* ctx, const double* drag_on, const double* drag_reaction, const double* rho,
+                                       const double* rho_dust) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(drag_on); NEED(drag_reaction); NEED(rho); NEED(rho_dust);
+    ctx->dev_drag_on = drag_on; ctx->dev_drag_re = drag_reaction; ctx->dev_drag_rho = rho; ctx->dev_drag_rhod = rho_dust;
+    return SPHX_OK;
+}
+
+// ---- species pass (nsc:624-627) + metallicity + AGB yields on owned + ghost arrays ---------------------------------------
+__global__ __launch_bounds__(256) void dev_gather_fun_kernel(int n, int S, int SP, const int* perm, const double* fun,
+                                                             const double* m, double* fun_s, double* m_s) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const size_t c = (size_t)perm[s];
+    for (int q = 0; q < SP; ++q) fun_s[(size_t)s * SP + q] = q < S ? fun[c * S + q] : 0.0;
+    m_s[s] = m[c];
+}
+__global__ __launch_bounds__(256) void dev_scatter_species_kernel(int n, int S, const int* perm, int n_keep, const double* in,
+                                                                  double* out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int c = perm[s];
+    if (c >= n_keep) return;
+    for (int q = 0; q < S; ++q) out[(size_t)q * n + c] = in[(size_t)q * n + s];
+}
+extern "C" int sphx_dev_set_agb(sphx_ctx* ctx, int nspecies, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx,
+                                const double* ty, const double* coeffs, const int32_t* mapto, double divisor,
+                                const double* mu_specie, double solar_mass) {
+    if (!ctx) return SPHX_E_ARG;
+    return sphx_agb_table_set(ctx, nspecies, nspl, ntx, nty, tx, ty, coeffs, mapto, divisor, mu_specie, solar_mass);
+}
+// after sphx_dev_prep: f_un (n_total,S) and mass (n_total,), ghosts included -> F (S,n_total) species-major, and with a
+// table set Z (n_total,) and agb_dust (n_total,S); owned entries written; Z / agb_dust may be NULL
+extern "C" int sphx_dev_species(sphx_ctx* ctx, int nspecies, const double* f_un, const double* mass, double* F, double* Z,
+                                double* agb_dust) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(f_un); NEED(mass); NEED(F);
+    if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_species before sphx_dev_search");
+    if (nspecies < 1 || nspecies > SPHX_MAX_SPECIES) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_species: %d species", nspecies);
+    if ((Z || agb_dust) && !(ctx->agb_on && Z && agb_dust && ctx->agb.nspec == nspecies))
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_species: Z / agb_dust need both pointers and a table for %d species", nspecies);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    const int S = nspecies, SP = (S + 15) & ~15;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    StateArrays& st = ctx->alt;
+    SPHX_TRY(sphx_ensure(ctx, st.fun, (size_t)n * SP * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, st.m, (size_t)n * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->F, (size_t)n * S * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->Zmet, (size_t)n * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double)));
+    hipLaunchKernelGGL(dev_gather_fun_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, S, SP, ctx->map_perm, f_un, mass,
+                       st.fun.as<double>(), st.m.as<double>());
+    SPHX_TRY(sphx_species_on(ctx, n, ctx->k, S, SP, st.fun.as<double>(), st.m.as<double>(), ctx->F.as<double>(),
+                             Z ? ctx->Zmet.as<double>() : nullptr, Z ? ctx->agb_dust.as<double>() : nullptr));
+    hipLaunchKernelGGL(dev_scatter_species_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, S, ctx->map_perm,
+                       ctx->map_nactive, ctx->F.as<double>(), F);
+    if (Z) {
+        hipLaunchKernelGGL(dev_scatter_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive,
+                           1, ctx->Zmet.as<double>(), Z);
+        hipLaunchKernelGGL(dev_scatter_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive,
+                           S, ctx->agb_dust.as<double>(), agb_dust);
+    }
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -374,7 +501,7 @@ extern "C" int sphx_sync(sphx_ctx* ctx) {
 //   regroup:  out_f[t]   = fields_f[sel[t]]           for t <  n_sel     (sel == NULL: identity)
 //             out_f[t]   = rows[t - n_sel, col_f ...] for t >= n_sel
 // Elements are copied as 8-byte words (double, or int64 ids).
-#define ROWS_MAX_FIELDS 16
+#define ROWS_MAX_FIELDS 24
 struct RowFields {
     int nf, W;
     const double* src[ROWS_MAX_FIELDS];

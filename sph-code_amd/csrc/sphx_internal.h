@@ -120,6 +120,8 @@ struct sphx_ctx {
     const int* qorder = nullptr;    // nullptr: identity
     DevBuf porder, mcount, mstart;
     bool use_blob = true;
+    // device-pointer API: drag terms handed to the next sphx_dev_integrate* call (sphx_dev_set_drag_terms)
+    const double *dev_drag_on = nullptr, *dev_drag_re = nullptr, *dev_drag_rho = nullptr, *dev_drag_rhod = nullptr;
     // species pass inside the step (nsc:624-627) + per-particle metallicity + fused AGB yields (sphx_state_set_agb)
     bool agb_on = false;
     AgbTable agb;
@@ -288,6 +290,10 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F);
 int sphx_step_species(sphx_ctx* ctx, int64_t n, int k);
+int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun_sorted, const double* m_sorted, double* F,
+                    double* Z, double* agb);
+int sphx_agb_table_set(sphx_ctx* ctx, int S, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx, const double* ty,
+                       const double* coeffs, const int32_t* mapto, double divisor, const double* mu_specie, double solar_mass);
 int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmajor);
 
 // integrate / layout helpers (sphx_integrate.hip)

@@ -578,6 +578,22 @@ __global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int 
     for (int t = 0; t < S; ++t) agb_out[(size_t)i * S + t] = dust[t];
 }
 
+// the species pass on any set of sorted arrays (the step: the resident state; the device API: gathered copies)
+int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun_sorted, const double* m_sorted, double* F,
+                    double* Z, double* agb) {
+    const int agb_on = (ctx->agb_on && Z && agb) ? 1 : 0;
+    if (S <= 16)       // the reference's 15 species: sums in 16 registers
+        hipLaunchKernelGGL(step_species_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun_sorted, ctx->qorder,
+                           m_sorted, ctx->agb, agb_on, F, Z, agb);
+    else
+        hipLaunchKernelGGL(step_species_kernel<SPHX_MAX_SPECIES>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (int)n, (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun_sorted, ctx->qorder,
+                           m_sorted, ctx->agb, agb_on, F, Z, agb);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 int sphx_step_species(sphx_ctx* ctx, int64_t n, int k) {
     const int S = ctx->s;
     SPHX_TRY(sphx_ensure(ctx, ctx->F, (size_t)n * S * sizeof(double)));
@@ -585,16 +601,6 @@ int sphx_step_species(sphx_ctx* ctx, int64_t n, int k) {
         SPHX_TRY(sphx_ensure(ctx, ctx->Zmet, (size_t)n * sizeof(double)));
         SPHX_TRY(sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double)));
     }
-    if (S <= 16)       // the reference's 15 species: sums in 16 registers
-        hipLaunchKernelGGL(step_species_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                           (int)sphx_pad64(n), k, S, ctx->sp, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), ctx->st.fun.as<double>(),
-                           ctx->qorder, ctx->st.m.as<double>(), ctx->agb, ctx->agb_on ? 1 : 0, ctx->F.as<double>(),
+    return sphx_species_on(ctx, n, k, S, ctx->sp, ctx->st.fun.as<double>(), ctx->st.m.as<double>(), ctx->F.as<double>(),
                            ctx->Zmet.as<double>(), ctx->agb_dust.as<double>());
-    else
-        hipLaunchKernelGGL(step_species_kernel<SPHX_MAX_SPECIES>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                           (int)sphx_pad64(n), k, S, ctx->sp, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), ctx->st.fun.as<double>(),
-                           ctx->qorder, ctx->st.m.as<double>(), ctx->agb, ctx->agb_on ? 1 : 0, ctx->F.as<double>(),
-                           ctx->Zmet.as<double>(), ctx->agb_dust.as<double>());
-    HIPCHK(hipGetLastError());
-    return SPHX_OK;
 }

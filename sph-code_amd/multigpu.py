@@ -259,14 +259,15 @@ class LibBackend:
         self._keep = (pos, vel, m, h, T, mu, gam, ptype)
         self._chk(self.lib.sphx_dev_prep(self.ctx.h, *[self._p(t) for t in self._keep]))
 
-    def density(self):
+    def density(self, want_dust=False):
         n, dev = self.n_total, self.device
         # the passes write every owned particle's entry straight into these (no copy); ghosts' entries are
         # either filled by the halo exchange (rho, m Pi) or never read
         rho = torch.empty(n, dtype=torch.float64, device=dev)
         nden = torch.empty(n, dtype=torch.float64, device=dev)
         ha = torch.empty((n, 3), dtype=torch.float64, device=dev)
-        self._chk(self.lib.sphx_dev_density(self.ctx.h, self._p(rho), None, self._p(nden), self._p(ha)))
+        self.rhod = torch.empty(n, dtype=torch.float64, device=dev) if want_dust else None
+        self._chk(self.lib.sphx_dev_density(self.ctx.h, self._p(rho), self._p(self.rhod), self._p(nden), self._p(ha)))
         return rho, nden, ha
 
     def pi(self, rho_complete):
@@ -292,6 +293,48 @@ class LibBackend:
                                                    self._p(ptype), self._p(ha), self._p(va), self._p(vh),
                                                    self._p(red2), 1 if first else 0, float(fixed_dt), self._p(dt)))
         return dt
+
+    # ---- gas-dust drag (nsc:719-742) and the species pass (nsc:624-627, + metallicity and AGB yields) ----
+    def drag(self, m, ptype, mgm, mcs):
+        """-> (drag_on (n_total,3): owned rows; drag_reaction (n_total,3): every row, ghosts' rows go back to their owners)."""
+        n, dev = self.n_total, self.device
+        onto = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        react = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+        self._keep_drag = (m, ptype, mgm, mcs)
+        self._chk(self.lib.sphx_dev_drag(self.ctx.h, self._p(m), self._p(ptype), self._p(mgm), self._p(mcs), self._p(onto),
+                                         self._p(react)))
+        return onto, react
+
+    def set_drag_terms(self, onto, react, rho, rhod):
+        self._keep_terms = (onto.contiguous(), react.contiguous(), rho.contiguous(), rhod.contiguous())
+        self._chk(self.lib.sphx_dev_set_drag_terms(self.ctx.h, *[self._p(t) for t in self._keep_terms]))
+
+    def set_agb(self, nspecies, table, mu_specie, solar_mass):
+        splines, mapto, divisor = table
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        ntx = i32([sp.get_knots()[0].size for sp in splines]); nty = i32([sp.get_knots()[1].size for sp in splines])
+        cat = lambda parts: f64(np.concatenate([np.asarray(q, dtype=np.float64).ravel() for q in parts]))
+        tx = cat([sp.get_knots()[0] for sp in splines]); ty = cat([sp.get_knots()[1] for sp in splines])
+        cf = cat([sp.get_coeffs() for sp in splines]); mp = i32(mapto); mu = f64(mu_specie[:nspecies])
+        p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        self._chk(self.lib.sphx_dev_set_agb(self.ctx.h, int(nspecies), len(splines), p32(ntx), p32(nty), dp(tx), dp(ty), dp(cf),
+                                            p32(mp), float(divisor), dp(mu), float(solar_mass)))
+        self.has_agb = True
+
+    def species(self, fun, m):
+        """-> (F (S,n_total), Z (n_total,) | None, agb_dust (n_total,S) | None); owned entries are meaningful."""
+        n, dev = self.n_total, self.device
+        S = int(fun.shape[1])
+        F = torch.zeros((S, n), dtype=torch.float64, device=dev)
+        Z = A = None
+        if getattr(self, "has_agb", False):
+            Z = torch.zeros(n, dtype=torch.float64, device=dev)
+            A = torch.zeros((n, S), dtype=torch.float64, device=dev)
+        fun = fun.contiguous()
+        self._chk(self.lib.sphx_dev_species(self.ctx.h, S, self._p(fun), self._p(m), self._p(F), self._p(Z), self._p(A)))
+        return F, Z, A
 
     # ---- the loop forms of the reference's time loop (drv:451-458) on owned + ghost arrays ----
     def loop_prep(self, pos, vel, m, T, mu, gam, ptype, E, d):
@@ -349,7 +392,8 @@ class DistributedSim:
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
     def __init__(self, state, lo, hi, backend, rank=0, world=1, device="cpu", comm_device=None,
-                 halo_scale=1.15, skin_frac=0.15, need_grid=96, migrate_every=4, forms="hydro_update", d=None):
+                 halo_scale=1.15, skin_frac=0.15, need_grid=96, migrate_every=4, forms="hydro_update", d=None,
+                 with_drag=False, with_species=False, agb=None):
         """forms: the sums of the step - "hydro_update" (nsc:556-671; four halo phases) or "loop", the loop forms the
         reference's time loop calls (drv:451-458, smoothing length from the driver's global `d`, drv:68; three halo
         phases: state + E, h_j, rho_j - no Pi_j)."""
@@ -358,6 +402,13 @@ class DistributedSim:
         if forms == "loop" and not (d is not None and d > 0):
             raise ValueError("forms='loop' needs the driver's global d (code_running.py:67-68)")
         self.forms, self.d = forms, (float(d) if d is not None else None)
+        # with_drag: the dust -> gas drag of nsc.net_impulse in the step (drv:455,462-463,473): ghosts carry their mean
+        # grain mass / cross-section, and the reaction scatter-added onto ghost neighbours travels back to their owners
+        # (the reverse halo).  with_species: every step forms f_un_neighbor (nsc:624-627) for the owned particles (ghosts
+        # carry their composition rows); agb = (splines, mapto, divisor): also the metallicity and the AGB yields.
+        self.with_drag, self.with_species, self.agb = bool(with_drag), bool(with_species or agb is not None), agb
+        if (self.with_drag or self.with_species) and state.get("f_un") is None:
+            raise ValueError("with_drag / with_species need a state with f_un")
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
         self.comm_device = torch.device(comm_device) if comm_device is not None else self.device
@@ -372,6 +423,19 @@ class DistributedSim:
         self.s["acc"] = f(acc) if acc is not None else torch.zeros((n, 3), dtype=torch.float64, device=self.device)
         self.s["h"] = torch.zeros(n, dtype=torch.float64, device=self.device)
         self.s["gid"] = torch.as_tensor(np.asarray(state["gid"], dtype=np.int64)).to(self.device)
+        self.extra_fields = []                  # per-particle fields beyond the core set: migrate and travel as ghosts
+        if self.with_drag:
+            from . import compat
+            fu = np.asarray(state["f_un"], dtype=np.float64)
+            self.s["mgm"] = f(np.sum(compat.grain_mass() * fu, axis=1))          # nsc:725
+            self.s["mcs"] = f(np.sum(compat.sigma_effective() * fu, axis=1))     # nsc:726
+            self.extra_fields += ["mgm", "mcs"]
+        if self.with_species:
+            self.s["fun"] = f(state["f_un"])
+            self.extra_fields += ["fun"]
+            if agb is not None and hasattr(backend, "set_agb"):
+                from . import compat
+                backend.set_agb(int(self.s["fun"].shape[1]), agb, compat.mu_specie, compat.solar_mass)
         self.lo = torch.as_tensor(lo, dtype=torch.float64).to(self.device)
         self.hi = torch.as_tensor(hi, dtype=torch.float64).to(self.device)
         self.halo_scale = halo_scale
@@ -595,6 +659,35 @@ class DistributedSim:
         self.last_ntotal = None
         return order if order.numel() == no else None
 
+    def _reverse_add(self, send_idx, recv_counts, ghost_rows, owned_acc):
+        """The reverse halo: rows accumulated on my ghosts go back to their owners, who add them to the particles they
+        sent (a particle sent to several peers collects from each; fixed order of addition)."""
+        if self.world == 1:
+            return
+        W = int(ghost_rows.shape[1])
+        bufs, o = [], 0
+        for p in range(self.world):
+            c = 0 if p == self.rank else int(recv_counts[p])
+            bufs.append(None if p == self.rank else ghost_rows[o:o + c])
+            o += c
+        back = [0 if ix is None else int(ix.numel()) for ix in send_idx]
+        got = self.ex.rows(bufs, back, W)
+        for p in range(self.world):
+            if got[p] is not None and back[p]:
+                owned_acc.index_add_(0, send_idx[p], got[p].to(owned_acc.device))
+
+    def _step_extras(self, be, no, ng, send_idx, recv_counts, m, ptype, extra, rho, rhod):
+        """Drag (nsc:719-742; the completed terms are handed to the coming update) and the species pass (nsc:624-627)."""
+        if self.with_drag:
+            onto, react = be.drag(m, ptype, extra["mgm"], extra["mcs"])
+            own = react[:no].clone()
+            self._reverse_add(send_idx, recv_counts, react[no:].contiguous(), own)
+            be.set_drag_terms(onto[:no], own, rho[:no], rhod[:no])
+        if self.with_species:
+            F, Z, A = be.species(extra["fun"], m)
+            self.last_species = dict(f_un_neighbor=F[:, :no], metallicity=None if Z is None else Z[:no],
+                                     agb_dust=None if A is None else A[:no])
+
     def step(self, fixed_dt=0.0):
         """One decomposed pass of the hot path.
 
@@ -652,11 +745,13 @@ class DistributedSim:
             state_fields = [s["pos"], s["vel"], s["m"], s["T"], s["mu"], s["gam"], s["ptype"], s["h"]]
             if loop:
                 state_fields.append(s["E"])               # del_pressure reads the neighbour's E (nsc:755)
+            state_fields += [s[k_] for k_ in self.extra_fields]       # drag coefficients / composition rows of the ghosts
             with self._sec("halo_state"):
                 g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
                 regrouped = self._regroup(None, no, g, state_fields)
                 pos, vel, m, T, mu, gam, ptype, hint = regrouped[:8]
                 E_all = regrouped[8] if loop else None
+                extra = dict(zip(self.extra_fields, regrouped[(9 if loop else 8):]))
             with self._sec("search"):
                 h = be.search(pos, no, hint, mean_h)
             f64 = dict(dtype=torch.float64, device=h.device)
@@ -676,15 +771,20 @@ class DistributedSim:
                     self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)  # rho_j (nsc:803)
                     va, vh, ct = be.loop_pass2(rho)
                     ha = None
+                    if self.with_drag or self.with_species:      # both read hydro_update's records (complete h)
+                        be.prep(pos, vel, m, h, T, mu, gam, ptype)
+                    self._step_extras(be, no, ng, send_idx, recv_counts, m, ptype, extra, rho, rhod)
             else:
               with self._sec("sums+halo_scalars"):
                 self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)        # h_j
                 be.prep(pos, vel, m, h, T, mu, gam, ptype)
-                rho, nden, ha = be.density()
+                rho, nden, ha = be.density(True) if self.with_drag else be.density()
                 self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)    # rho_j
                 bw, ct = be.pi(rho)
                 self._exchange(send_idx, recv_counts, [bw[:no]], into=tail(bw), send_cat=self.send_cat)      # m Pi_j
                 va, vh = be.visc(bw, m)
+                self._step_extras(be, no, ng, send_idx, recv_counts, m, ptype, extra, rho,
+                                  getattr(be, "rhod", None) if self.with_drag else None)
             # ---- ONE reduction and ONE host read for the step's scalars: halo verdict (max), global
             # minimum crossing time for dt (nsc:786, drv:222-229; as max of the negative), max / mean h
             t_dt = time.perf_counter()
@@ -775,7 +875,8 @@ class DistributedSim:
         if not self.last or self.last["rho"].shape[0] != n:
             z = torch.zeros(n, dtype=torch.float64, device=self.device)
             self.last = dict(rho=z, nden=z.clone(), visc_heat=z.clone())
-        fields = [s[k_] for k_ in self.MIG_FIELDS] + [self.last[k_] for k_ in ("rho", "nden", "visc_heat")]
+        mig = list(self.MIG_FIELDS) + list(self.extra_fields)
+        fields = [s[k_] for k_ in mig] + [self.last[k_] for k_ in ("rho", "nden", "visc_heat")]
         order = self._cell_order()
         got = None
         sel = order
@@ -805,7 +906,7 @@ class DistributedSim:
             return                                             # nothing moved, no order to apply
         n_sel = n if sel is None else int(sel.numel())
         new = self._regroup(sel, n_sel, got, fields)
-        for k_, v in zip(self.MIG_FIELDS, new):
+        for k_, v in zip(mig, new):
             s[k_] = v
         self.last = dict(rho=new[-3], nden=new[-2], visc_heat=new[-1])
 
@@ -818,7 +919,59 @@ class DistributedSim:
         if self.last:
             out.update(densities=c(self.last["rho"]), num_densities=c(self.last["nden"]),
                        visc_heat=c(self.last["visc_heat"]))
+        sp = getattr(self, "last_species", None)
+        if sp:
+            out.update({k_: c(v) for k_, v in sp.items() if v is not None})
         return out
+
+
+    # ---- snapshot / restart and per-step diagnostics (for the decomposed run) -------------------------
+    def snapshot(self, prefix):
+        """Every rank writes `<prefix>.rank<r>.npz`: its owned particles (dynamic and static arrays, global ids) and what
+        a restart needs of the driver's state (region boxes, step mode, first-step flag, last dt and mean / max h)."""
+        s = self.s
+        c = lambda t: t.detach().cpu().numpy()
+        out = dict(gid=c(s["gid"]), points=c(s["pos"]), velocities=c(s["vel"]), total_accel=c(s["acc"]), E_internal=c(s["E"]),
+                   T=c(s["T"]), sizes=c(s["h"]), mass=c(s["m"]), mu_array=c(s["mu"]), gamma_array=c(s["gam"]),
+                   particle_type=c(s["ptype"]), lo=c(self.lo), hi=c(self.hi), first=np.int64(1 if self.first else 0),
+                   dt_last=np.float64(self.dt_last), hmean_prev=np.float64(self.hmean_prev), hmax_prev=np.float64(self.hmax_prev),
+                   world=np.int64(self.world), forms=np.array(self.forms), d=np.float64(self.d if self.d is not None else 0.0),
+                   steps=np.int64(self.stats["steps"]))
+        np.savez("%s.rank%d.npz" % (prefix, self.rank), **out)
+        if self.world > 1:
+            dist.barrier()
+
+    @classmethod
+    def from_snapshot(cls, prefix, backend, rank=0, world=1, **kw):
+        """Resume a decomposed run written by snapshot() with the same number of ranks."""
+        z = dict(np.load("%s.rank%d.npz" % (prefix, rank), allow_pickle=False))
+        if int(z["world"]) != world:
+            raise ValueError("snapshot was written by %d ranks, resuming with %d" % (int(z["world"]), world))
+        state = {k_: z[k_] for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "mass", "mu_array",
+                                       "gamma_array", "particle_type", "gid")}
+        forms = str(z["forms"])
+        sim = cls(state, z["lo"], z["hi"], backend, rank, world, forms=forms, d=(float(z["d"]) if forms == "loop" else None), **kw)
+        sim.s["h"] = torch.as_tensor(np.ascontiguousarray(z["sizes"], dtype=np.float64)).to(sim.device)
+        sim.first = bool(int(z["first"]))
+        sim.dt_last = float(z["dt_last"])
+        sim.hmean_prev, sim.hmax_prev = float(z["hmean_prev"]), float(z["hmax_prev"])
+        sim.stats["steps"] = int(z["steps"])
+        return sim
+
+    def diagnostics(self):
+        """Global mass-weighted net acceleration (what sph/code_running.py:465-468 prints every step), momentum, kinetic
+        and internal energy, particle count: one all_reduce(sum) of 9 numbers."""
+        s = self.s
+        m = s["m"]
+        loc = torch.cat([(s["acc"] * m[:, None]).sum(dim=0), (s["vel"] * m[:, None]).sum(dim=0),
+                         torch.stack([m.sum(), 0.5 * (m * (s["vel"] ** 2).sum(dim=1)).sum(), s["E"].sum(),
+                                      torch.tensor(float(self.n_owned), dtype=torch.float64, device=m.device)])])
+        if self.world > 1:
+            loc = loc.to(self.comm_device)
+            dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+        v = loc.tolist()
+        return dict(net_accel=np.array(v[0:3]) / v[6], momentum=np.array(v[3:6]), kinetic=v[7], internal=v[8],
+                    particles=int(round(v[9])), dt=self.dt_last)
 
 
 def decompose_state(state, world, rank):
@@ -829,6 +982,8 @@ def decompose_state(state, world, rank):
     for key in ("points", "velocities", "mass", "particle_type", "T", "mu_array", "gamma_array", "E_internal",
                 "total_accel"):
         mine[key] = np.ascontiguousarray(state[key][sel])
+    if state.get("f_un") is not None:
+        mine["f_un"] = np.ascontiguousarray(np.asarray(state["f_un"], dtype=np.float64)[sel])
     mine["gid"] = sel.astype(np.int64)
     return mine, lo, hi
 
@@ -865,16 +1020,27 @@ def bench_main(args, rank, local_rank, world):
         if getattr(args, "natural_size", False) and n_global > 1e6:
             scale = (n_global / 1e6) ** (1. / 3.)
             dilution = "constant density: x%.3g in length" % scale
-    state = ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale)
+    species, drag = bool(getattr(args, "species", False)), bool(getattr(args, "drag", False))
+    full = species or drag                           # these need the (N,15) composition
+    state = (ics.WORKLOADS[args.workload](n_global, size_scale=scale) if full
+             else ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale))
+    if full and state.get("f_un") is None:
+        raise SystemExit("--species / --drag need a workload that carries f_un (two_phase, dusty_sphere)")
+    agb_table = None
+    if species:
+        from . import agb as agb_mod
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "agb_reference.npz"))
+        agb_table = agb_mod.splines_from_arrays(z["tx"], z["ty"], z["coeffs"], z["mapto"], float(z["divisor"]))
     d_loop = ics.loop_d(state, args.k) if forms == "loop" else None
     # the same workload at the per-GPU size on ONE GPU through the fused single-GPU loop (rank 0, before the decomposed
     # run): the denominator a scaling efficiency for THIS workload needs, measured in the same process
     single = None
     if rank == 0 and world > 1 and os.environ.get("SPHX_BENCH_SINGLE", "1") != "0":
         from .sim import Simulation
-        s1 = ics.WORKLOADS[args.workload](args.n, light=True, size_scale=1.0 if dilution.startswith("none") else ics.bench_size_scale(args.n))
+        sc1 = 1.0 if dilution.startswith("none") else ics.bench_size_scale(args.n)
+        s1 = ics.WORKLOADS[args.workload](args.n, size_scale=sc1) if full else ics.WORKLOADS[args.workload](args.n, light=True, size_scale=sc1)
         sim1 = Simulation(s1, n_neigh=args.k, device=dev_index, forms=forms, d=ics.loop_d(s1, args.k) if forms == "loop" else None,
-                          clip_grad=getattr(args, "clip_grad", False))
+                          clip_grad=getattr(args, "clip_grad", False), with_species=species, agb=agb_table, with_drag=drag)
         sim1.step(3)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -887,7 +1053,8 @@ def bench_main(args, rank, local_rank, world):
     mine, lo, hi = decompose_state(state, world, rank)
     del state
     be = LibBackend(dev_index, k=args.k, clip_grad=getattr(args, "clip_grad", False))
-    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev, forms=forms, d=d_loop)
+    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev, forms=forms, d=d_loop,
+                         with_drag=drag, with_species=species, agb=agb_table)
     for _ in range(args.warmup):
         sim.step()
     sim.ex.bytes_sent = 0
@@ -927,11 +1094,12 @@ def bench_main(args, rank, local_rank, world):
                        "particles_per_gpu": args.n,
                        "decomposition": "recursive coordinate bisection, %d regions, %d-phase p2p halo" % (world, 3 if forms == "loop" else 4),
                        "backend": backend, "cloud_size_scale": scale, "dilution": dilution,
-                       "forms": forms + (" (the reference's time loop: nsc.density, del_pressure, artificial_viscosity ...)" if forms == "loop" else "")},
+                       "forms": forms + (" (the reference's time loop: nsc.density, del_pressure, artificial_viscosity ...)" if forms == "loop" else ""),
+                       "species_pass": species, "drag": drag},
             "single_gpu_same_workload": single,
             "state_check": {"finite": float(chk[1]) == 0.0, "max_speed_m_s": float(chk[0]),
                             "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
-            "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "knn_kernel<0,2> (rank 0)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,
+            "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "search (rank 0): knn_group_kernel + knn_kernel<0,2,1> (list mode)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,
                                         "peak": 8000.0, "unit": "GB/s", "frac": 192.0 * q / (ms * 1e-3) / 1e9 / 8000.0,
                                         "traffic": None, "algorithmic_bytes_per_launch": 192.0 * q,
                                         "kernel_ms": ms, "queries_per_launch": q})(

@@ -68,20 +68,27 @@ def test_one_rank_device_api_matches_fused_step_in_loop_form_mode():
         np.testing.assert_allclose(b[key][order], a[key], rtol=1e-13, atol=0, err_msg=key)
 
 
-def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update"):
+def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update", c5=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sph_code_amd.ics as ics
     from sph_code_amd import multigpu as mg
-    state = ics.WORKLOADS[workload](n, light=True)
+    state = ics.WORKLOADS[workload](n) if c5 else ics.WORKLOADS[workload](n, light=True)
     mine, lo, hi = mg.decompose_state(state, world, rank)
     kw = dict(forms="loop", d=ics.loop_d(state, K)) if forms == "loop" else {}
+    if c5:        # BASELINE configs[4]'s ingredients: drag with its reverse halo, species pass, metallicity, AGB yields
+        import sph_code_amd.agb as agb
+        g = np.load(os.path.join(ROOT, "tests", "golden", "agb_reference.npz"))
+        kw.update(with_drag=True, with_species=True,
+                  agb=agb.splines_from_arrays(g["tx"], g["ty"], g["coeffs"], g["mapto"], float(g["divisor"])))
     sim = mg.DistributedSim(mine, lo, hi, mg.LibBackend(0, k=K), rank, world, device="cuda:0", comm_device="cpu", **kw)
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
+    if "f_un_neighbor" in res:
+        res["f_un_neighbor"] = np.ascontiguousarray(res["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
     res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
                              sim.stats.get("replans", 0)])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
@@ -140,6 +147,51 @@ def test_two_ranks_sharing_one_gpu_loop_forms_on_the_reference_ic(tmp_path):
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
     assert sum(p["stats"][0] for p in parts) > 0
+
+
+@pytest.mark.parametrize("forms", ["hydro_update", "loop"])
+def test_two_ranks_sharing_one_gpu_drag_species_agb(forms, tmp_path):
+    """BASELINE configs[4]'s ingredients in the decomposed step: two-phase gas + dust (drv:120-152), the gas-dust drag with its
+    reverse halo (nsc:741: reaction onto ghost neighbours goes back to their owners), the species pass (nsc:624-627) with the
+    metallicity and the AGB yields fused in - two ranks sharing the GPU, against the single-domain oracle, in both step modes."""
+    from oracle import sph_oracle as orc
+    from oracle import agb_oracle as ao
+    import sph_code_amd.ics as ics
+    n, nsteps, world = 12000, 3, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, nsteps, "two_phase", str(tmp_path), forms, True), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    gid = np.concatenate([p["gid"] for p in parts])
+    assert np.array_equal(np.sort(gid), np.arange(n))
+    order = np.argsort(gid)
+    got = {k_: np.concatenate([p[k_] for p in parts])[order]
+           for k_ in ("points", "velocities", "E_internal", "sizes", "densities", "f_un_neighbor", "metallicity", "agb_dust")}
+    ref = ics.two_phase(n)
+    d = ics.loop_d(ref, K)
+    prev = None
+    for it in range(nsteps):
+        prev = ref
+        ref = (orc.step_loop(ref, d, n_neigh=K, eps=0.0, first=(it == 0), with_drag=True) if forms == "loop"
+               else orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0), with_drag=True))
+    assert float(parts[0]["dt"]) == pytest.approx(ref["dt"], rel=1e-12)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-10)
+    assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * np.max(np.abs(ref["points"]))
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-7 * np.max(np.abs(ref["velocities"]))
+    # the last step's species sums, metallicity and yields (on the state that step started from)
+    p, v = orc.clamp_state(prev["points"], prev["velocities"])
+    F = orc.hydro_update(ref["neighbor"], p, prev["mass"], ref["sizes"], prev["f_un"], prev["particle_type"], prev["T"],
+                         prev["mu_array"], prev["gamma_array"], v)[5]
+    np.testing.assert_allclose(got["f_un_neighbor"].T, F, rtol=1e-11, atol=0)
+    mu = orc.MU_SPECIE
+    with np.errstate(all="ignore"):
+        Z = (F[6:] * mu[6:, None]).sum(axis=0) / (F * mu[:, None]).sum(axis=0)
+    fin = np.isfinite(Z)
+    np.testing.assert_allclose(got["metallicity"][fin], Z[fin], rtol=1e-10, atol=1e-300)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "agb_reference.npz"))
+    dust, _ = ao.calculate_interpolation(prev["mass"][fin], got["metallicity"][fin], (list(g["tx"]), list(g["ty"]), list(g["coeffs"])),
+                                         mu, np.ones((fin.sum(), 15)), mapto=g["mapto"], divisor=float(g["divisor"]))
+    np.testing.assert_allclose(got["agb_dust"][fin], dust, rtol=1e-12, atol=0)
 
 
 @pytest.mark.gpu

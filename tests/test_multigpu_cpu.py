@@ -40,9 +40,39 @@ class OracleBackend:
         pos, vel, m, h, T, mu, gam, ptype = self.a
         return self.orc.hydro_update(self.nb, pos, m, h, np.ones((len(pos), 1)), ptype, T, mu, gam, vel, **kw)
 
-    def density(self):
+    def density(self, want_dust=False):
         out = self._hu()
+        self.rhod = torch.from_numpy(out[6].copy()) if want_dust else None
         return torch.from_numpy(out[3].copy()), torch.from_numpy(out[4].copy()), torch.from_numpy(out[0].copy())
+
+    # ---- drag (nsc:719-742) with the mean grain mass / cross-section given per particle; ghost QUERIES contribute
+    # nothing (their sums belong to their owners), ghost NEIGHBOURS collect reaction (sent back by the driver) ----
+    def drag(self, m, ptype, mgm, mcs):
+        o = self.orc
+        pos, vel, m_, h, T, mu, gam, pt = self.a
+        n = len(pos)
+        nb = self.nb.copy()
+        nb[self.no:] = np.arange(self.no, n)[:, None]
+        pts, nb, dx, r2 = o._loop_geometry(pos, nb)
+        dv = vel[nb] - vel[:, None, :]
+        mg, mc = mgm.numpy(), mcs.numpy()
+        with np.errstate(all="ignore"):
+            wf = o._weigh2_dust(r2, m_[nb], h[nb])
+            coef = wf / mg[nb] * mc[nb] * np.sum(dv ** 2, axis=2) ** 0.5 * (pt[nb] == 2) * (wf > 0)
+            acc = coef[..., None] * dv
+        onto = np.sum(acc, axis=1)
+        react = np.zeros((n, 3))
+        notself = (nb != np.arange(n)[:, None])
+        np.add.at(react, nb.ravel(), (-(acc * notself[..., None])).reshape(-1, 3))
+        return torch.from_numpy(onto), torch.from_numpy(react)
+
+    def set_drag_terms(self, onto, react, rho, rhod):
+        self.terms = (onto.numpy().copy(), react.numpy().copy(), rho.numpy().copy(), rhod.numpy().copy())
+
+    def species(self, fun, m):
+        pos, vel, m_, h, T, mu, gam, pt = self.a
+        F = self.orc.hydro_update(self.nb, pos, m_, h, fun.numpy(), pt, T, mu, gam, vel)[5]
+        return torch.from_numpy(np.ascontiguousarray(F)), None, None
 
     def pi(self, rho_complete):
         self.rho_c = rho_complete.numpy()
@@ -95,8 +125,10 @@ class OracleBackend:
 
     def integrate(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt):
         n = lambda t: t.numpy()[:no]
+        drag = getattr(self, "terms", None)
+        self.terms = None
         p, v, tot, En, Tn = self.orc.integrate(n(pos), n(vel), n(acc), n(E), n(m), n(mu), n(gam), n(ptype),
-                                               n(ha), n(va), n(vh), dt)
+                                               n(ha), n(va), n(vh), dt, None, drag)
         for dst, src in ((pos, p), (vel, v), (acc, tot), (E, En), (T, Tn)):
             dst[:no] = torch.from_numpy(np.ascontiguousarray(src))
 
@@ -117,15 +149,18 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, sim_kw=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sph_code_amd.ics as ics
     from sph_code_amd import multigpu as mg
-    state = ics.WORKLOADS[workload](n, light=True)
-    mine, lo, hi = mg.decompose_state(state, world, rank)
     sim_kw = dict(sim_kw or {})
+    full = bool(sim_kw.get("with_drag") or sim_kw.get("with_species"))
+    state = ics.WORKLOADS[workload](n) if full else ics.WORKLOADS[workload](n, light=True)
+    mine, lo, hi = mg.decompose_state(state, world, rank)
     if sim_kw.get("forms") == "loop":
         sim_kw["d"] = ics.loop_d(state, K)
     sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **sim_kw)
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
+    if "f_un_neighbor" in res:
+        res["f_un_neighbor"] = np.ascontiguousarray(res["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
     res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
                              sim.stats.get("replans", 0)])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
@@ -141,7 +176,8 @@ def _run_world(world, n, nsteps, workload, tmp_path, sim_kw=None):
     assert np.array_equal(np.sort(gid), np.arange(n)), "particles lost or duplicated"
     order = np.argsort(gid)
     merged = {k_: np.concatenate([p[k_] for p in parts])[order]
-              for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities")}
+              for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities", "f_un_neighbor")
+              if k_ in parts[0]}
     merged["dt"] = [float(p["dt"]) for p in parts]
     merged["stats"] = np.sum([p["stats"] for p in parts], axis=0)
     return merged
@@ -278,3 +314,71 @@ def test_world2_gloo_loop_forms_on_the_reference_ic(tmp_path):
     np.testing.assert_allclose(got["velocities"], ref["velocities"], rtol=1e-11, atol=1e-9)
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-12)
     assert got["stats"][0] > 0
+
+
+def _snap_worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sph_code_amd.ics as ics
+    from sph_code_amd import multigpu as mg
+    state = ics.polytrope_sphere(n, light=True)
+    mine, lo, hi = mg.decompose_state(state, world, rank)
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu")
+    sim.step(); sim.step()
+    prefix = os.path.join(out_dir, "snap")
+    sim.snapshot(prefix)
+    diag = sim.diagnostics()
+    sim.step(); sim.step()
+    a = sim.owned_numpy()
+    sim2 = mg.DistributedSim.from_snapshot(prefix, OracleBackend(K), rank, world, device="cpu")
+    assert not sim2.first and sim2.stats["steps"] == 2
+    sim2.step(); sim2.step()
+    b = sim2.owned_numpy()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), diag_net=diag["net_accel"], diag_n=diag["particles"],
+             diag_kin=diag["kinetic"], **{"a_" + k_: v for k_, v in a.items()}, **{"b_" + k_: v for k_, v in b.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_snapshot_restart_and_diagnostics(tmp_path):
+    """A decomposed run resumed from its per-rank snapshots continues like the uninterrupted one (the plan is rebuilt:
+    same neighbour sets, same sums); the diagnostics are global sums (every rank reports the same numbers)."""
+    n, world = 2400, 2
+    port = _free_port()
+    mp.spawn(_snap_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    assert int(parts[0]["diag_n"]) == int(parts[1]["diag_n"]) == n
+    assert np.array_equal(parts[0]["diag_net"], parts[1]["diag_net"]) and float(parts[0]["diag_kin"]) > 0
+    for key in ("points", "velocities", "sizes", "densities", "E_internal"):
+        a = np.concatenate([p["a_" + key] for p in parts])[np.argsort(np.concatenate([p["a_gid"] for p in parts]))]
+        b = np.concatenate([p["b_" + key] for p in parts])[np.argsort(np.concatenate([p["b_gid"] for p in parts]))]
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-9 if key == "velocities" else 0, err_msg=key)
+
+
+def test_world2_gloo_drag_with_reverse_halo_and_species(tmp_path):
+    """A dusty sphere over two ranks with the gas-dust drag in the step (nsc:719-742, drv:455,462-463,473): ghosts carry their
+    drag coefficients, the reaction scatter-added onto ghost neighbours (nsc:741) travels back to the owners - the reverse
+    halo - and the result is the single-domain oracle step's; the species pass (nsc:624-627) of the last step likewise."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    n, nsteps = 3000, 3
+    got = _run_world(2, n, nsteps, "dusty_sphere", tmp_path, sim_kw=dict(with_drag=True, with_species=True))
+    ref = ics.dusty_sphere(n)
+    prev = None
+    for it in range(nsteps):
+        prev = ref
+        ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0), with_drag=True)
+    assert got["dt"][0] == got["dt"][1] == pytest.approx(ref["dt"], rel=1e-14)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-14)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-12)
+    np.testing.assert_allclose(got["velocities"], ref["velocities"], rtol=1e-10, atol=1e-9)
+    assert np.abs(ref["velocities"] - orc.step(prev, n_neigh=K, eps=0.0, first=False)["velocities"]).max() > 0   # drag acted
+    # species sums of the last step: on the state the step started from
+    p, v = orc.clamp_state(prev["points"], prev["velocities"])
+    F = orc.hydro_update(ref["neighbor"], p, prev["mass"], ref["sizes"], prev["f_un"], prev["particle_type"], prev["T"],
+                         prev["mu_array"], prev["gamma_array"], v)[5]
+    np.testing.assert_allclose(got["f_un_neighbor"].T, F, rtol=1e-12, atol=0)
