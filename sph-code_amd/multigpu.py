@@ -1010,7 +1010,7 @@ def bench_main(args, rank, local_rank, world):
         comm_dev = torch.device("cpu")
     n_global = args.n * world                       # weak scaling: fixed particles per GPU
     forms = getattr(args, "forms", None) or "hydro_update"
-    if forms == "loop" and args.workload == "uniform_cube":
+    if forms == "loop" and args.workload in ("uniform_cube", "two_phase"):
         # BASELINE configs[3] as written: the reference's own IC (uniform cube of side 1.25e6 AU, drv:62,132) at its
         # natural size, stepped by the loop forms its time loop calls (drv:451-458) - stable, no dilution
         scale, dilution = 1.0, "none (natural size)"
