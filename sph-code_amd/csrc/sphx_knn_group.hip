@@ -504,18 +504,23 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         // further apart than 2 tol + 2 bins are in their true order
         const u32 win = okq ? (u32)(2.0 * tol_q * 2097152.0) + 3u : 0u;
         const u32 nextfirst = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key[0], 0x39, 0xF, 0xF, false);  // quad_perm [1,2,3,0]: lane + 1
-        bool amb = false;
+        // A particle that was NOT listed has d2 > R^2 (1.0002 - tol) in truth: the K-th listed one must lie below that with
+        // the same margin again, or an unlisted particle could be the true K-th (the list is then too short in truth)
+        const u32 safe = okq ? (u32)(2097152.0 * (1.0 - 2.0 * tol_q / 1.0002)) - 2u : 0u;
+        bool amb = false, edge = false;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int r = part * 16 + u;
             const u32 nxt = (u < 15) ? key[(u + 1) & 15] : (part < 3 ? nextfirst : 0xFFFFFFFFu);
             if (r < K && nxt != 0xFFFFFFFFu && (nxt >> 11) - (key[u] >> 11) <= win) amb = true;
+            if (r == K - 1 && (key[u] >> 11) > safe) edge = true;
         }
         // any of the query's four lanes
-        int am = amb ? 1 : 0;
+        int am = (amb ? 1 : 0) | (edge ? 2 : 0);
         am |= __builtin_amdgcn_update_dpp(0, am, 0xB1, 0xF, 0xF, true);
         am |= __builtin_amdgcn_update_dpp(0, am, 0x4E, 0xF, 0xF, true);
-        if (okq && am && !a.exp_noamb) { okq = false; failq = true; q_why = 6; }
+        if (okq && (am & 2)) { okq = false; failq = true; q_why = 5; }
+        if (okq && (am & 1) && !a.exp_noamb) { okq = false; failq = true; q_why = 6; }
     }
     KG_STAMP(5)
     // ---- outputs: rank r = 16 part + u ----
