@@ -74,6 +74,8 @@ typedef struct sphx_stats {
     double  ms_gravity;    /* self-gravity (0 unless sphx_state_set_gravity)    */
     int64_t fallback_queries; /* last step: queries the grouped search left to the general kernel */
     double  ms_species;    /* species pass of the step (+ metallicity, AGB yields); ms_density excludes it */
+    int64_t short_rows;    /* searches that gave up after the last radius of the retry ladder with fewer than K
+                              neighbours although more particles exist (pathological states only; 0 otherwise) */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */

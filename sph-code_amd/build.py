@@ -14,8 +14,8 @@ LIB = os.path.join(HERE, "libsphx.so")
 SOURCES = ["sphx_api.hip", "sphx_grid.hip", "sphx_knn.hip", "sphx_knn_group.hip", "sphx_sums.hip",
            "sphx_integrate.hip", "sphx_loopforms.hip", "sphx_dev.hip", "sphx_refresh.hip", "sphx_blob.hip",
            "sphx_agb.hip", "sphx_gravity.hip"]
-HEADERS = [os.path.join(CSRC, "sphx_internal.h"), os.path.join(CSRC, "sphx_wave.h"), os.path.join(CSRC, "sphx_blob.h"), os.path.join(CSRC, "sphx_leapfrog.h"), os.path.join(CSRC, "sphx_knn_group.h"),
-           os.path.join(os.path.dirname(HERE), "include", "sphx.h")]
+HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "sphx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -676,6 +676,7 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.candidates = (int64_t)sc[SC_CAND];
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
     ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
+    ctx->stats.short_rows = (int64_t)sc[SC_SHORT];
     if (getenv("SPHX_KG_DEBUG"))
         fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu | groups over the row cap %llu, over the pre-cull cap %llu\n",
                 sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6],
@@ -821,6 +822,7 @@ extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
     SPHX_TRY(sphx_dev_collect(ctx));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_CAND, 0, 2 * sizeof(u64), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_SHORT, 0, sizeof(u64), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }

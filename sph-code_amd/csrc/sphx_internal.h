@@ -242,6 +242,7 @@ enum {
     SC_HCNT = 7,      // f64: number of h values in SC_HSUM
     SC_GRAV_EPS = 8,  // f64: gravitational softening = median(h) of this step (nsc:358)
     SC_NFAILQ = 9,    // u32: queries of the last hinted search left to the general kernel
+    SC_SHORT = 10,    // u64: searches that gave up (KNN_MAX_TRIES radii) with fewer than K neighbours although more exist
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
     SC_NSLOTS = 24
 };

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     unsigned char* rflag = row_flag[wave];
     int* rbase = row_base[wave];
     for (int q = lane; q < KNN_FLAG_CAP / 4; q += 64) reinterpret_cast<u32*>(rflag)[q] = 0u;
-    u64 ncand = 0, nretry = 0;
+    u64 ncand = 0, nretry = 0, nshort = 0;
 
     do {
     // list mode: 4 queries per wave and pass instead of 16 - the list is short (a few per cent of the queries), so
@@ -386,6 +386,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             }
             saw_all = covers;
             done = full || covers || at_bound || (++tries >= KNN_MAX_TRIES);
+            if (ABL == 0 && !full && !covers && !at_bound && tries >= KNN_MAX_TRIES) ++nshort;   // gave up short: reported
             if (ABL != 0) done = true;    // timing experiments never retry
             if (!done) {
                 R *= 1.6;
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     if (lane == 0 && a.counters) {
         atomicAdd(&a.counters[SC_CAND], ncand);
         if (nretry) atomicAdd(&a.counters[SC_RETRY], nretry);
+        if (nshort) atomicAdd(&a.counters[SC_SHORT], nshort);
     }
 }
 

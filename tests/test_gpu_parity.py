@@ -810,6 +810,7 @@ def test_grouped_search_equals_general_search(workload, n, K, steps, kw, monkeyp
     assert fb["general"] == 0
     if workload == "polytrope":
         assert 0 < fb["grouped"] < 0.1 * n          # the grouped kernel really did certify nearly all of them
+        assert sim.stats()["short_rows"] == 0       # no search gave up with a short row (sphx_stats.short_rows)
     for name in ("general", "grouped_morton"):
         for key in ("points", "velocities", "E_internal", "T", "sizes", "densities", "total_accel"):
             assert np.array_equal(res["grouped"][key], res[name][key], equal_nan=True), (name, key)
