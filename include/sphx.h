@@ -76,6 +76,8 @@ typedef struct sphx_stats {
     double  ms_species;    /* species pass of the step (+ metallicity, AGB yields); ms_density excludes it */
     int64_t short_rows;    /* searches that gave up after the last radius of the retry ladder with fewer than K
                               neighbours although more particles exist (pathological states only; 0 otherwise) */
+    int64_t far_queries;   /* last hinted search but one: queries outside the grid box with a search sphere wider than 8 cells */
+    int64_t outlier_levels;/* last hinted search: nested outlier levels it was given (0: none built) */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */

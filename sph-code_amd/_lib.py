@@ -23,7 +23,8 @@ class SphxStats(C.Structure):
                [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
                                          "rebuild_steps")] + \
                [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64),
-                ("ms_species", C.c_double), ("short_rows", C.c_int64)]
+                ("ms_species", C.c_double), ("short_rows", C.c_int64), ("far_queries", C.c_int64),
+                ("outlier_levels", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -85,6 +85,8 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
+    if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
     if (const char* e = getenv("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
     if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
@@ -161,6 +163,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
         if (ctx->lag_hev[r]) (void)hipEventDestroy(ctx->lag_hev[r]);
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->olev_ev) (void)hipEventDestroy(ctx->olev_ev);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -677,6 +680,20 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
     ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
     ctx->stats.short_rows = (int64_t)sc[SC_SHORT];
+    if (getenv("SPHX_KNN_PROF")) {
+        const char* nm[4] = {"in-box", "-", "outside the box", "-"};
+        for (int c = 0; c < 4; ++c)
+            if (sc[SC_KNNPROF + 4 + c])
+                fprintf(stderr, "[sphx] general search, %-17s: %9llu queries, %8.0f cycles each, longest %10llu, %.2f tries each\n", nm[c],
+                        sc[SC_KNNPROF + 4 + c], (double)sc[SC_KNNPROF + c] / (double)sc[SC_KNNPROF + 4 + c], sc[SC_KNNPROF + 8 + c],
+                        (double)sc[SC_KNNPROF + 12 + c] / (double)sc[SC_KNNPROF + 4 + c]);
+        const double* dbg = (const double*)(sc + SC_KNNPROF + 16);
+        if (dbg[7] > 0.0)
+            fprintf(stderr, "[sphx]   a long one: at (%.4g %.4g %.4g), radius given %.4g, found h %.4g, %g retries, %g candidates, %g cycles | box origin (%.4g %.4g %.4g) cell %.4g dims %d %d %d\n",
+                    dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], ctx->grid.xmin, ctx->grid.ymin, ctx->grid.zmin,
+                    ctx->grid.cell, ctx->grid.nx, ctx->grid.ny, ctx->grid.nz);
+        HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_KNNPROF, 0, 24 * sizeof(u64), ctx->stream));
+    }
     if (getenv("SPHX_KG_DEBUG"))
         fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu | groups over the row cap %llu, over the pre-cull cap %llu\n",
                 sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6],

@@ -436,7 +436,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         cell *= 1.02 * cbrt((double)tot / (double)cap);
     }
     GridParams& g = ctx->grid;
-    (void)tmin; (void)tmax;
+    for (int c = 0; c < 3; ++c) { ctx->tbox_h[c] = tmin[c]; ctx->tbox_h[3 + c] = tmax[c]; }
+    ctx->olev.L = 0;                   // (outlier levels belong to one grid: rebuilt on demand, sphx_build_outlier_levels)
     ctx->tbox = ctx->bbox_tmp.as<double>() + (size_t)RED_MAXBLOCKS * BB_W;   // bbox_final's min/max
     g.xmin = bb[0]; g.ymin = bb[1]; g.zmin = bb[2];
     g.cell = cell; g.inv_cell = 1.0 / cell;
@@ -512,6 +513,88 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
                            ctx->perm.as<int>());
     }
     HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// ---- outlier levels (OutLevels, sphx_internal.h) ---------------------------------------------------
+// level and cell of a position outside the grid box: the lowest level whose cube holds it
+__device__ __forceinline__ int olev_key_of(const OutLevels& o, double x, double y, double z) {
+    const double ax = fabs(x - o.cx), ay = fabs(y - o.cy), az = fabs(z - o.cz);
+    const double m = fmax(fmax(ax, ay), az) / o.hmax;      // Chebyshev distance from the centre in units of hmax
+    int e = 0;
+    (void)frexp(m, &e);                                    // m = f 2^e, f in [0.5, 1): m <= 2^e
+    int lev = (m == m && m <= 1.7e308) ? e : o.L;
+    lev = lev < 1 ? 1 : (lev > o.L ? o.L : lev);
+    const double W = ldexp(o.hmax, lev);                   // half-width of the level's cube
+    const double ic = (double)OLEV_N / (2.0 * W);
+    const double nm1 = (double)(OLEV_N - 1);
+    const int cx = (int)fmin(fmax((x - (o.cx - W)) * ic, 0.0), nm1);
+    const int cy = (int)fmin(fmax((y - (o.cy - W)) * ic, 0.0), nm1);
+    const int cz = (int)fmin(fmax((z - (o.cz - W)) * ic, 0.0), nm1);
+    return ((lev - 1) * OLEV_N + cz) * OLEV_N * OLEV_N + cy * OLEV_N + cx;
+}
+__global__ __launch_bounds__(256) void olev_count(int n, const double* x, const double* y, const double* z, GridParams g,
+                                                  OutLevels o, int* key, int* hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    int kx = -1;
+    if (sphx_outside_box(g, xi, yi, zi)) {
+        kx = olev_key_of(o, xi, yi, zi);
+        atomicAdd(&hist[kx], 1);
+    }
+    key[i] = kx;
+}
+__global__ __launch_bounds__(256) void olev_scatter(int n, const int* key, const int* start, int* hist, int* list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int kx = key[i];
+    if (kx < 0) return;
+    list[start[kx] + atomicSub(&hist[kx], 1) - 1] = i;     // (arrival order: the search ranks candidates by (d^2, index))
+}
+
+// Levels for the current grid over the cell-sorted positions.  The number of levels follows the true bounding box the
+// grid build knew (a step old in the fused loop: whatever has moved beyond the top cube since sits in its boundary cells).
+int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const double* ys, const double* zs) {
+    const GridParams& g = ctx->grid;
+    OutLevels& o = ctx->olev;
+    o.L = 0;
+    const double ex = 0.5 * g.nx * g.cell, ey = 0.5 * g.ny * g.cell, ez = 0.5 * g.nz * g.cell;
+    o.cx = g.xmin + ex; o.cy = g.ymin + ey; o.cz = g.zmin + ez;
+    o.hmax = fmax(fmax(ex, ey), ez);
+    if (!(o.hmax > 0.0) || !isfinite(o.hmax)) return SPHX_OK;
+    double ext = 0.0;
+    const double c3[3] = {o.cx, o.cy, o.cz};
+    for (int c = 0; c < 3; ++c) {
+        const double a = fabs(ctx->tbox_h[c] - c3[c]), b = fabs(ctx->tbox_h[3 + c] - c3[c]);
+        if (isfinite(a) && a > ext) ext = a;
+        if (isfinite(b) && b > ext) ext = b;
+    }
+    int L = 1;
+    while (L < OLEV_MAX && ldexp(o.hmax, L) < 2.0 * ext) ++L;    // (one level of head-room for this step's motion)
+    const size_t ncell = (size_t)L * OLEV_N * OLEV_N * OLEV_N;
+    SPHX_TRY(sphx_ensure(ctx, ctx->olev_start, (ncell + 2) * sizeof(int)));
+    const size_t cap0 = ctx->olev_fill.cap;
+    SPHX_TRY(sphx_ensure(ctx, ctx->olev_fill, ((size_t)OLEV_MAX * OLEV_N * OLEV_N * OLEV_N + 2) * sizeof(int)));
+    if (ctx->olev_fill.cap != cap0) ctx->olev_fill_zeroed = nullptr;
+    SPHX_TRY(sphx_ensure(ctx, ctx->olev_list, (size_t)n * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->olev_key, (size_t)n * sizeof(int)));
+    int* fill = ctx->olev_fill.as<int>();
+    if (ctx->olev_fill_zeroed != ctx->olev_fill.p) {          // counted up by olev_count, back down by olev_scatter
+        HIPCHK(hipMemsetAsync(fill, 0, ctx->olev_fill.cap, ctx->stream));
+        ctx->olev_fill_zeroed = ctx->olev_fill.p;
+    }
+    OutLevels ok = o;
+    ok.L = L;
+    const int pb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(olev_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, xs, ys, zs, g, ok, ctx->olev_key.as<int>(), fill);
+    SPHX_TRY(excl_scan_plus_total(ctx, fill, ctx->olev_start.as<int>(), (int)ncell));
+    hipLaunchKernelGGL(olev_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n, ctx->olev_key.as<int>(),
+                       ctx->olev_start.as<int>(), fill, ctx->olev_list.as<int>());
+    HIPCHK(hipGetLastError());
+    o.L = L;
+    o.start = ctx->olev_start.as<int>();
+    o.list = ctx->olev_list.as<int>();
     return SPHX_OK;
 }
 

@@ -60,6 +60,28 @@ struct GridParams {
     float fnx1, fny1, fnz1;       // (float)(nx - 1) ...: kernel arguments cost no VALU conversions
 };
 
+// Outlier levels (sphx_grid.hip, sphx_knn.hip): nested cubes around the grid box, each OLEV_N^3 cells, level l reaching
+// hmax * 2^l from the box centre along every axis; the particles OUTSIDE the grid box are listed per (level, cell), each in
+// the lowest level whose cube holds it (everything beyond the top cube is clamped into its boundary cells).  The grid
+// itself still holds every particle (outliers in its boundary cells), so the levels are a second, complete index of
+// the outliers only: a far query with a wide search sphere walks a few coarse cells instead of whole faces of the grid.
+#define OLEV_N 32
+#define OLEV_MAX 20
+#define OLEV_MIN_RC 8.0f     // a query outside the box uses the levels when its search radius exceeds this many grid cells
+struct OutLevels {
+    int L;                   // levels 1..L (0: none built)
+    double cx, cy, cz;       // centre of the grid box
+    double hmax;             // half of its longest edge
+    const int* start;        // [L * OLEV_N^3 + 1]: slice of `list` per (level - 1, cell)
+    const int* list;         // storage indices of the outliers
+};
+// position of a particle relative to the grid box in cell units, exactly as the cell hash computes it (sub, then mul: no
+// contraction possible), so "outside" means the same in the grid build, the level build and the search
+__device__ __forceinline__ bool sphx_outside_box(const GridParams& g, double x, double y, double z) {
+    const double tx = (x - g.xmin) * g.inv_cell, ty = (y - g.ymin) * g.inv_cell, tz = (z - g.zmin) * g.inv_cell;
+    return tx < 0.0 || tx >= (double)g.nx || ty < 0.0 || ty >= (double)g.ny || tz < 0.0 || tz >= (double)g.nz;
+}
+
 // device-resident particle state, structure of arrays (one set; `alt` is the permute target)
 struct StateArrays {
     DevBuf x, y, z, vx, vy, vz, ax, ay, az;      // position, velocity, previous total accel
@@ -134,6 +156,23 @@ struct sphx_ctx {
     bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
     bool knn_hinted = false;        // set by the callers of sphx_knn whose rsearch holds real previous radii
     DevBuf fail_list;               // queries the grouped kernel hands to the general one (+ their count)
+    // outlier levels (see OutLevels): built for a hinted search when the previous one met enough far queries
+    int olev_mode = 2;              // SPHX_OUTLIER_LEVELS: 0 never, 1 whenever a particle lies outside the box, 2 auto
+    OutLevels olev;                 // olev.L == 0: not built for the current grid
+    DevBuf olev_start, olev_fill, olev_list, olev_key;
+    const void* olev_fill_zeroed = nullptr;
+    double tbox_h[6] = {0, 0, 0, 0, 0, 0};   // host copy of the true bounding box the last grid build knew (may lag a step)
+    hipEvent_t olev_ev = nullptr;   // recorded behind the copy of SC_FARQ to the host
+    bool olev_ev_valid = false;
+    u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
+    int64_t farq_last = 0;          // far queries met by the previous hinted search
+    // hint distrust: when the previous hinted search left more than a quarter of its queries to the general kernel (a
+    // diverging run: particles move by several h per step, the previous radii say nothing) the next ones skip the
+    // grouped kernel and seed every radius from the local cell counts; back to normal once the radii found agree with
+    // the hints again (fewer than 5 % beyond [0.5, 1.5] x hint)
+    bool distrust = false;
+    u64 badhint_seen = 0;
+    int distrust_mode = 2;          // SPHX_HINT_DISTRUST: 0 never, 1 always, 2 auto
     int blob_curve = 0;             // 0: Hilbert where its code space fits, 1: Morton always (SPHX_BLOB_CURVE)
     // sphx_blob.hip: per-workgroup distinct-neighbour lists + 16-bit slot lists for the LDS passes
     DevBuf slot16, uniq;
@@ -243,8 +282,11 @@ enum {
     SC_GRAV_EPS = 8,  // f64: gravitational softening = median(h) of this step (nsc:358)
     SC_NFAILQ = 9,    // u32: queries of the last hinted search left to the general kernel
     SC_SHORT = 10,    // u64: searches that gave up (KNN_MAX_TRIES radii) with fewer than K neighbours although more exist
+    SC_FARQ = 11,     // u64, only grows: queries outside the grid box with a search sphere wider than OLEV_MIN_RC cells
+    SC_BADHINT = 12,  // u64, only grows: hinted queries (distrust mode) whose radius came out beyond [0.5, 1.5] x the hint
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
-    SC_NSLOTS = 24
+    SC_KNNPROF = 24,  // u64[16]: general search, cycles / queries / longest / tries by query class (-DSPHX_KNN_PROF builds)
+    SC_NSLOTS = 48
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------
@@ -267,6 +309,7 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits);
 int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
+int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const double* ys, const double* zs);   // (sorted order)
 // knn
 struct KnnOut {
     int32_t* nbr;       // [k][npad] sorted indices (nullable)

@@ -54,6 +54,8 @@ struct KnnArgs {
     // search (sphx_knn_group.hip) could not certify; the grid is fixed and walks the list
     const int* qlist;
     const int* qcount;
+    OutLevels ol;              // OUTL = 1: the outlier levels of the current grid (ol.L >= 1)
+    int distrust;              // hints are upper bounds at best: every radius is seeded from the local cell counts
 };
 
 #include "sphx_wave.h"
@@ -116,6 +118,31 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
     return (int)t;
 }
 
+// particles and cells in the (clipped) 3x3x3 block of cells around (xi, yi, zi): lanes 0..8 read one x-run each
+__device__ __forceinline__ void block27_count(const GridParams& g, const int* cell_start, double xi, double yi, double zi,
+                                              int lane, int& cnt_out, int& nc_out) {
+    const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
+    const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
+    const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
+    int cnt = 0, nc = 0;
+    if (lane < 9) {
+        int cy = cyi - 1 + lane % 3, cz = czi - 1 + lane / 3;
+        if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+            int xlo = max(cxi - 1, 0), xhi = min(cxi + 1, g.nx - 1);
+            int row = (cz * g.ny + cy) * g.nx;
+            cnt = cell_start[row + xhi + 1] - cell_start[row + xlo];
+            nc = xhi - xlo + 1;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        nc += __shfl_xor(nc, o, 64);
+    }
+    cnt_out = __shfl(cnt, 0, 64);
+    nc_out = __shfl(nc, 0, 64);
+}
+
 #ifndef KNN_MIN_WAVES
 #define KNN_MIN_WAVES 6      // waves per SIMD the register budget is held to (6 -> <= 80 VGPRs; measured fastest)
 #endif
@@ -124,8 +151,14 @@ __device__ __forceinline__ int cell_coord(double v, double vmin, double inv_cell
 // LEAN = 1: the step loop's variant - only the K-major list and h (sorted order) are produced,
 // so the API / Verlet-list pointers are never loaded (17 pointers in SGPRs otherwise: measured
 // 20 % slower).  LEAN = 2: the same for the device API (h written by id).
-template <int ABL, int LEAN = 0, int LIST = 0>
-__global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
+// OUTL = 1 (list mode only): a query OUTSIDE the grid box whose search sphere is wider than OLEV_MIN_RC cells does not walk
+// the grid's boundary faces (every escaper hashed there: whole faces of one-particle rows) but the outlier levels its
+// sphere can reach (OutLevels) and then the grid with the outliers filtered out - the same candidates, each exactly once.
+#ifndef KNN_LIST_WAVES
+#define KNN_LIST_WAVES 4     // list / outlier-level variants: fewer, fatter waves (the prefetched batch needs registers)
+#endif
+template <int ABL, int LEAN = 0, int LIST = 0, int OUTL = 0>
+__global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     extern __shared__ int tile_dyn[];                 // [K][KNN_PPB + 1] result tile (sized at launch)
 #define tile(kk, li) tile_dyn[(kk) * (KNN_PPB + 1) + (li)]
     __shared__ u64 stg_key[KNN_BLOCK / 64][128];
@@ -146,7 +179,10 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
     unsigned char* rflag = row_flag[wave];
     int* rbase = row_base[wave];
     for (int q = lane; q < KNN_FLAG_CAP / 4; q += 64) reinterpret_cast<u32*>(rflag)[q] = 0u;
-    u64 ncand = 0, nretry = 0, nshort = 0;
+    u64 ncand = 0, nretry = 0, nshort = 0, nfar = 0, nbad = 0;
+#ifdef SPHX_KNN_PROF
+    u64 p_sum[2] = {0, 0}, p_n[2] = {0, 0}, p_max[2] = {0, 0}, p_tries[2] = {0, 0};
+#endif
 
     do {
     // list mode: 4 queries per wave and pass instead of 16 - the list is short (a few per cent of the queries), so
@@ -182,31 +218,46 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         double R = bcast_f64(qr, t16);
         if (!(R > 0.0)) {
             // density estimate from the 3x3x3 block of cells around the particle
-            const int cxi = cell_coord(xi, g.xmin, g.inv_cell, g.nx - 1);
-            const int cyi = cell_coord(yi, g.ymin, g.inv_cell, g.ny - 1);
-            const int czi = cell_coord(zi, g.zmin, g.inv_cell, g.nz - 1);
-            int cnt = 0, nc = 0;
-            if (lane < 9) {
-                int cy = cyi - 1 + lane % 3, cz = czi - 1 + lane / 3;
-                if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-                    int xlo = max(cxi - 1, 0), xhi = min(cxi + 1, g.nx - 1);
-                    int row = (cz * g.ny + cy) * g.nx;
-                    cnt = a.cell_start[row + xhi + 1] - a.cell_start[row + xlo];
-                    nc = xhi - xlo + 1;
-                }
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                cnt += __shfl_xor(cnt, o, 64);
-                nc += __shfl_xor(nc, o, 64);
-            }
-            cnt = __shfl(cnt, 0, 64);
-            nc = __shfl(nc, 0, 64);
+            int cnt, nc;
+            block27_count(g, a.cell_start, xi, yi, zi, lane, cnt, nc);
             double vol = (double)nc * g.cell * g.cell * g.cell;
             double dens = (double)(cnt > 0 ? cnt : 1) / vol;
             R = 1.3 * cbrt((double)K / (4.1887902047863905 * dens));
         }
         if (R > a.rbound) R = a.rbound;
+        // list mode: is the query outside the grid box (wave-uniform)?  Counted when its sphere is wide (SC_FARQ: the host
+        // builds the outlier levels for the next search when there are many), served by the levels when OUTL
+        const bool q_out = (LIST || OUTL || a.distrust) && sphx_outside_box(g, xi, yi, zi);
+        const double R_given = R;
+        bool far_counted = false;
+#ifdef SPHX_KNN_PROF
+        const long long prof_t0 = clock64();
+        const u64 prof_c0 = ncand;
+        int prof_cat = q_out ? 3 : 0;
+#endif
+        // A stale hint: the particle has moved (a diverging run moves it by several h per step) into a neighbourhood far
+        // denser than its previous radius implies - the 3x3x3 block of cells around it alone holds many times what a sphere
+        // of that radius should.  The hinted sphere would then cover thousands of times the candidates needed (the whole
+        // cloud for an escaper flying back through the core): start from the block's density estimate instead and climb
+        // towards the hint only if that comes up short.
+        double R_hint = 0.0;              // > 0: the ladder climbs back to it before it goes beyond
+        if ((LIST || a.distrust) && !q_out) {
+            const double rc = R * g.inv_cell;
+            if (rc > 3.0 || a.distrust) {
+                int cnt, nc;
+                block27_count(g, a.cell_start, xi, yi, zi, lane, cnt, nc);
+                if (cnt < 1) cnt = 1;
+                const double expect = (double)K * (double)nc / (4.1887902047863905 * rc * rc * rc);
+                if (a.distrust || (double)cnt > 4.0 * expect + 8.0) {
+                    const double dens = (double)cnt / ((double)nc * g.cell * g.cell * g.cell);
+                    const double Re = 1.3 * cbrt((double)K / (4.1887902047863905 * dens));
+                    if (Re < R) { R_hint = R; R = Re; }
+#ifdef SPHX_KNN_PROF
+                    if (R_hint > 0.0) prof_cat = 1;
+#endif
+                }
+            }
+        }
 
         u64 bk;
         u32 bv;
@@ -221,28 +272,82 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             const bool at_bound = (R >= a.rbound);
             u64 tk = (u64)__double_as_longlong(R * R) + (at_bound ? 0ull : 1ull);
             const double R2 = R * R;
-            // Query position and radius in CELL units: fp64 once, then all range geometry in fp32.
+            int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
+            bool have_best = false;           // best[] still empty: first flush is a plain sort
+            // ---- which index structures this try walks: the grid alone, or (OUTL, far query) levels lv_hi .. lv_lo of
+            // the outliers and then the grid with the outliers filtered out
+            bool multi = false;
+            int lv_lo = 0, lv_hi = 0, lv_own = 0;
+            double Rcur = R;                  // radius still to be searched: shrinks to the K-th best once K are in hand
+            if (q_out && (float)(R * g.inv_cell) > OLEV_MIN_RC) {
+                if (!far_counted) { ++nfar; far_counted = true; }
+                if (OUTL) {
+                    // Chebyshev distance from the centre, in units of hmax, of the nearest / farthest point of the sphere
+                    // (|(|p|_inf - |q|_inf)| <= |p - q|_2), padded by 1e-9 against the rounding of the level build;
+                    // level 1 holds m < 2, level l holds [2^(l-1), 2^l), the top level everything from 2^(L-1) on
+                    const double mq = fmax(fmax(fabs(xi - a.ol.cx), fabs(yi - a.ol.cy)), fabs(zi - a.ol.cz));
+                    const double mlo = fmax(mq - R, 0.0) * (1.0 - 1e-9) / a.ol.hmax, mhi = (mq + R) * (1.0 + 1e-9) / a.ol.hmax;
+                    lv_lo = 1;
+                    while (lv_lo < a.ol.L && ldexp(1.0, lv_lo) <= mlo) ++lv_lo;          // levels below end before mlo
+                    lv_hi = lv_lo;
+                    while (lv_hi < a.ol.L && ldexp(1.0, lv_hi) <= mhi) ++lv_hi;          // levels above start beyond mhi
+                    // the query's own level goes first: its neighbours are most likely there, and with K of them in hand
+                    // the other structures are searched only out to the K-th (a stale, far too wide hint - an escaper
+                    // flying back past the core - then costs its own level, not the whole cloud)
+                    int e = 0;
+                    (void)frexp(mq / a.ol.hmax, &e);
+                    lv_own = e < lv_lo ? lv_lo : (e > lv_hi ? lv_hi : e);
+                    multi = true;
+#ifdef SPHX_KNN_PROF
+                    prof_cat = 2;
+#endif
+                }
+            }
+            bool own_done = false;
+            for (int lv = multi ? lv_own : 0;;) {
+            // Query position and radius in CELL units of this structure: fp64 once, then all range geometry in fp32.
             // Every fp32 quantity is padded (radius x(1+1e-5) + 2e-3 cells, distances - 1e-3 cells;
             // fp32 resolves 1.2e-4 cells at index 2047), so the clipped ranges can only grow: a
             // superset of the exact fp64 ranges, never a lost neighbour.
-            const float fx = (float)((xi - g.xmin) * g.inv_cell);
-            const float fy = (float)((yi - g.ymin) * g.inv_cell);
-            const float fz = (float)((zi - g.zmin) * g.inv_cell);
-            const float Rc = (float)(R * g.inv_cell) * 1.00001f + 2e-3f;
-            const float nx1 = g.fnx1, ny1 = g.fny1, nz1 = g.fnz1;
+            double ox = g.xmin, oy = g.ymin, oz = g.zmin, icell = g.inv_cell;
+            float nx1 = g.fnx1, ny1 = g.fny1, nz1 = g.fnz1;
+            int gnx = g.nx, gny = g.ny;
+            const int* cstart = a.cell_start;
+            const bool indirect = OUTL && lv > 0;         // candidate slots index the outlier list
+            const bool filter = OUTL && multi && lv == 0; // grid pass of a far query: outliers were seen in their levels
+            if (indirect) {
+                const double W = ldexp(a.ol.hmax, lv);
+                ox = a.ol.cx - W; oy = a.ol.cy - W; oz = a.ol.cz - W;
+                icell = (double)OLEV_N / (2.0 * W);
+                nx1 = ny1 = nz1 = (float)(OLEV_N - 1);
+                gnx = gny = OLEV_N;
+                cstart = a.ol.start + (size_t)(lv - 1) * (OLEV_N * OLEV_N * OLEV_N);
+            }
+            const float fx = (float)((xi - ox) * icell);
+            const float fy = (float)((yi - oy) * icell);
+            const float fz = (float)((zi - oz) * icell);
+            const float Rc = (float)(Rcur * icell) * 1.00001f + 2e-3f;
             // rows are tested against the query clamped into the grid: with it the half-infinite
-            // boundary cells need no special case (their open side can only lie behind the query)
-            const float fyc = fminf(fmaxf(fy, 0.0f), ny1 + 1.0f), fzc = fminf(fmaxf(fz, 0.0f), nz1 + 1.0f);
+            // boundary cells need no special case (their open side can only lie behind the query).  A structure of
+            // finite extent (the grid with the outliers filtered out, every level but the top one) holds nothing
+            // beyond its cube: there the true distances apply, and a sphere that misses the cube walks no rows
+            const bool finite = OUTL && multi && (lv == 0 || lv < a.ol.L);
+            const float fyc = finite ? fy : fminf(fmaxf(fy, 0.0f), ny1 + 1.0f), fzc = finite ? fz : fminf(fmaxf(fz, 0.0f), nz1 + 1.0f);
             const int cy0 = (int)fminf(fmaxf(fy - Rc, 0.0f), ny1);
             const int cy1 = (int)fminf(fmaxf(fy + Rc, 0.0f), ny1);
             const int cz0 = (int)fminf(fmaxf(fz - Rc, 0.0f), nz1);
             const int cz1 = (int)fminf(fmaxf(fz + Rc, 0.0f), nz1);
             const int ysp = cy1 - cy0 + 1;
-            const int nrows = __mul24(ysp, cz1 - cz0 + 1);
+            int nrows = __mul24(ysp, cz1 - cz0 + 1);
+            if (finite) {
+                const float ex = fmaxf(fmaxf(-fx, fx - (nx1 + 1.0f)), 0.0f), ey = fmaxf(fmaxf(-fy, fy - (ny1 + 1.0f)), 0.0f),
+                            ez = fmaxf(fmaxf(-fz, fz - (nz1 + 1.0f)), 0.0f);
+                // (relative padding: the coordinates of a far query are large numbers of cells)
+                if ((ex * ex + ey * ey + ez * ez) * 0.9999f > Rc * Rc) nrows = 0;
+            }
             const float inv_ysp = __builtin_amdgcn_rcpf((float)ysp);
-            const float Rc2 = Rc * Rc;
-            int nst = 0, head = 0;            // staging ring occupancy / head (wave-uniform)
-            bool have_best = false;           // best[] still empty: first flush is a plain sort
+            const bool flip_y = 2.0f * fy > (float)(cy0 + cy1 + 1), flip_z = 2.0f * fz > (float)(cz0 + cz1 + 1);
+            float Rc2 = Rc * Rc;             // shrinks with the running K-th best (rows and chords still to come are clipped to it)
 
             for (int rb = 0; rb < (ABL == 3 ? 0 : nrows); rb += 64) {
                 // ---- one lane per (cy,cz) row of cells: clip the row to the search SPHERE ----
@@ -254,7 +359,10 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     int ry = r - __mul24(rz, ysp);
                     if (ry < 0) { --rz; ry += ysp; }
                     if (ry >= ysp) { ++rz; ry -= ysp; }
-                    const int cy = cy0 + ry, cz = cz0 + rz;
+                    // rows on the query's side of the range first: with K candidates in hand the rest is clipped to the
+                    // K-th best, so a query far outside (its sphere a near-planar cut through the cloud) stops at the
+                    // depth where it found them instead of walking the whole cloud
+                    const int cy = flip_y ? cy1 - ry : cy0 + ry, cz = flip_z ? cz1 - rz : cz0 + rz;
                     // distance (in cells) from the query to the row's (y,z) cell column.  Boundary cells
                     // are half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
                     const float cyf = (float)cy, czf = (float)cz;
@@ -266,8 +374,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                         const int rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
                         const int rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
                         // < 2^23 cells in all: 24-bit multiplies, 32-bit byte offsets
-                        const int row = __mul24(__mul24(cz, g.ny) + cy, g.nx);
-                        const char* cs = (const char*)a.cell_start;
+                        const int row = __mul24(__mul24(cz, gny) + cy, gnx);
+                        const char* cs = (const char*)cstart;
                         s_row = *(const int*)(cs + ((u32)(row + rx0) << 2));
                         cnt = *(const int*)(cs + ((u32)(row + rx1 + 1) << 2)) - s_row;
                     }
@@ -293,7 +401,8 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     wave_sync();
                 }
                 int carry = 0;                // non-empty rows that started before this batch
-                for (int t0 = 0; t0 < (ABL == 2 ? 0 : T); t0 += 64) {
+                // candidate slots t0 .. t0+63 -> particle indices
+                auto slots_to_particles = [&](int t0) -> int {
                     const int t = t0 + lane;
                     const bool valid = t < T;
                     const int tt = valid ? t : 0;
@@ -314,12 +423,43 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                         }
                         p = __shfl(sb, rr, 64) + tt;
                     }
-                    // 32-bit byte offsets (n <= 2^29, checked by the launcher): scalar base + one VGPR
-                    const u32 boff = (u32)p << 3;
-                    const double d2 = dist2_nofma(*(const double*)((const char*)a.x + boff) - xi,
-                                                  *(const double*)((const char*)a.y + boff) - yi,
-                                                  *(const double*)((const char*)a.z + boff) - zi);
-                    const u64 key = (u64)__double_as_longlong(d2);
+                    if (indirect) p = valid ? a.ol.list[p] : 0;
+                    return p;
+                };
+                // list mode is bound by the latency of its longest queries (one wave walking thousands of batches): the
+                // next batch's positions are requested before this one's are looked at
+                constexpr bool PIPE = (LIST || OUTL) && ABL == 0;
+                int p_next = 0;
+                double nxp = 0.0, nyp = 0.0, nzp = 0.0;
+                if (PIPE && T > 0) {
+                    p_next = slots_to_particles(0);
+                    const u32 bo = (u32)p_next << 3;
+                    nxp = *(const double*)((const char*)a.x + bo); nyp = *(const double*)((const char*)a.y + bo);
+                    nzp = *(const double*)((const char*)a.z + bo);
+                }
+                for (int t0 = 0; t0 < (ABL == 2 ? 0 : T); t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool valid = t < T;
+                    int p;
+                    double cxp, cyp, czp;
+                    if (PIPE) {
+                        p = p_next; cxp = nxp; cyp = nyp; czp = nzp;
+                        if (t0 + 64 < T) {
+                            p_next = slots_to_particles(t0 + 64);
+                            const u32 bo = (u32)p_next << 3;
+                            nxp = *(const double*)((const char*)a.x + bo); nyp = *(const double*)((const char*)a.y + bo);
+                            nzp = *(const double*)((const char*)a.z + bo);
+                        }
+                    } else {
+                        p = slots_to_particles(t0);
+                        // 32-bit byte offsets (n <= 2^29, checked by the launcher): scalar base + one VGPR
+                        const u32 boff = (u32)p << 3;
+                        cxp = *(const double*)((const char*)a.x + boff); cyp = *(const double*)((const char*)a.y + boff);
+                        czp = *(const double*)((const char*)a.z + boff);
+                    }
+                    const double d2 = dist2_nofma(cxp - xi, cyp - yi, czp - zi);
+                    u64 key = (u64)__double_as_longlong(d2);
+                    if (filter && sphx_outside_box(g, cxp, cyp, czp)) key = KNN_INF;   // (never below the threshold)
                     // d2 >= 0 so the bit pattern orders like the value; NaN keys (> INF) never pass.
                     // ties in d2 are broken by the candidate's position in the cell-sorted order,
                     // which sphx_grid.hip makes deterministic (cells sorted by previous index)
@@ -350,7 +490,14 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                             // running threshold: the K-th best - or the 64th when the whole register
                             // set is kept as a Verlet list, which must then be exact to its last entry
                             const u64 kth = __shfl(bk, KT - 1, 64);
-                            if (kth != KNN_INF) tk = kth + 1ull;
+                            if (kth != KNN_INF) {
+                                tk = kth + 1ull;
+                                // nothing beyond the K-th best can still enter: clip what remains of this structure to it
+                                // (same padding as the trial radius; an oversized sphere - a stale hint, a ladder step too
+                                // far - then costs about what the right one would have)
+                                const float rk = (float)(sqrt(__longlong_as_double((long long)kth)) * icell) * 1.00001f + 2e-3f;
+                                Rc2 = fminf(Rc2, rk * rk);
+                            }
                         }
                     }
                 }
@@ -359,6 +506,41 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
                     if (ne) rflag[off] = 0;
                     wave_sync();
                 }
+            }
+            if (!OUTL || !multi || lv == 0) break;
+            // between structures: rank what is staged; with K candidates in hand nothing beyond the K-th can matter
+            if (nst > 0) {
+                wave_sync();
+                u64 ck; u32 cv;
+                sort_staged<ABL>(skey, sid, head, nst, R2, lane, ck, cv);
+                wave_sync();
+                head = (head + nst) & 127;
+                nst = 0;
+                if (have_best) {
+                    merge_sorted(bk, bv, ck, cv, lane);
+                } else {
+                    bk = ck; bv = cv;
+                    have_best = true;
+                }
+            }
+            {
+                const u64 kth_now = __shfl(bk, K - 1, 64);
+                if (kth_now != KNN_INF) {
+                    tk = kth_now + 1ull;
+                    const double rk = sqrt(__longlong_as_double((long long)kth_now)) * (1.0 + 1e-15);
+                    if (rk < Rcur) {
+                        Rcur = rk;
+                        const double mq = fmax(fmax(fabs(xi - a.ol.cx), fabs(yi - a.ol.cy)), fabs(zi - a.ol.cz));
+                        const double mlo = fmax(mq - Rcur, 0.0) * (1.0 - 1e-9) / a.ol.hmax, mhi = (mq + Rcur) * (1.0 + 1e-9) / a.ol.hmax;
+                        while (lv_lo < a.ol.L && ldexp(1.0, lv_lo) <= mlo) ++lv_lo;      // (the range can only narrow)
+                        while (lv_hi > lv_lo && ldexp(1.0, lv_hi - 1) > mhi) --lv_hi;
+                    }
+                }
+            }
+            // next structure: the levels from the top down (the own one is done), then the grid
+            if (!own_done) { own_done = true; lv = lv_hi + 1; }
+            do { --lv; } while (lv == lv_own && lv >= lv_lo);
+            if (lv < lv_lo) lv = 0;
             }
             if (nst > 0) {
                 wave_sync();
@@ -389,7 +571,19 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
             if (ABL == 0 && !full && !covers && !at_bound && tries >= KNN_MAX_TRIES) ++nshort;   // gave up short: reported
             if (ABL != 0) done = true;    // timing experiments never retry
             if (!done) {
-                R *= 1.6;
+                double grow = 1.6;
+                if (LIST || a.distrust) {
+                    // list mode: the short try's own count sizes the next step (c of K found inside R: uniform density
+                    // puts K inside R (K/c)^(1/3)), between the x1.6 of the general ladder and x3
+                    const int c = __popcll(__builtin_amdgcn_ballot_w64(bk != KNN_INF));
+                    grow = fmin(fmax(cbrt(1.5 * (double)K / (double)(c > 0 ? c : 1)), 1.6), 3.0);
+                }
+                if (R_hint > 0.0 && R < R_hint) {
+                    R = fmin(R * grow, R_hint);
+                    if (R >= R_hint) R_hint = 0.0;
+                } else {
+                    R *= grow;
+                }
                 if (R > a.rbound) R = a.rbound;
                 ++nretry;
             }
@@ -401,6 +595,20 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         const double d = valid ? sqrt(__longlong_as_double((long long)bk)) : 0.0;
         const double dlast = __shfl(d, found > 0 ? found - 1 : 0, 64);
         const double hval = found > 0 ? dlast : 0.0;
+#ifdef SPHX_KNN_PROF
+        {
+            const u64 dtc = (u64)(clock64() - prof_t0);
+            const int pc = prof_cat >= 2 ? 1 : 0;
+            p_sum[pc] += dtc; p_n[pc] += 1; p_tries[pc] += (u64)(tries + 1);
+            if (dtc > p_max[pc]) p_max[pc] = dtc;
+            if (dtc > 10000000ull && lane == 0 && a.counters) {        // a monster: who is it?
+                double* dbg = (double*)(a.counters + SC_KNNPROF + 16);
+                dbg[0] = xi; dbg[1] = yi; dbg[2] = zi; dbg[3] = R_given; dbg[4] = hval; dbg[5] = (double)tries;
+                dbg[6] = (double)(ncand - prof_c0); dbg[7] = (double)dtc;
+            }
+        }
+#endif
+        if (a.distrust && a.rsearch && (hval * a.rscale > 1.5 * R_given || hval * a.rscale < 0.5 * R_given)) ++nbad;
         if (lane < K) {
             if (LEAN || a.nbr) tile(lane, li) = valid ? (int)bv : -1;
             if (!LEAN && a.idx64) a.idx64[(long long)oid * K + lane] = valid ? (long long)a.id[bv] : (long long)a.n;
@@ -442,6 +650,17 @@ __global__ __launch_bounds__(KNN_BLOCK, KNN_MIN_WAVES) void knn_kernel(KnnArgs a
         atomicAdd(&a.counters[SC_CAND], ncand);
         if (nretry) atomicAdd(&a.counters[SC_RETRY], nretry);
         if (nshort) atomicAdd(&a.counters[SC_SHORT], nshort);
+        if (nfar) atomicAdd(&a.counters[SC_FARQ], nfar);
+        if (nbad) atomicAdd(&a.counters[SC_BADHINT], nbad);
+#ifdef SPHX_KNN_PROF
+        for (int pc = 0; pc < 2; ++pc)
+            if (p_n[pc]) {
+                atomicAdd(&a.counters[SC_KNNPROF + 2 * pc], p_sum[pc]);
+                atomicAdd(&a.counters[SC_KNNPROF + 4 + 2 * pc], p_n[pc]);
+                atomicMax(&a.counters[SC_KNNPROF + 8 + 2 * pc], p_max[pc]);
+                atomicAdd(&a.counters[SC_KNNPROF + 12 + 2 * pc], p_tries[pc]);
+            }
+#endif
     }
 }
 
@@ -498,6 +717,8 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     a.qlist = nullptr; a.qcount = nullptr;
+    a.distrust = 0;
+    a.ol.L = 0; a.ol.start = nullptr; a.ol.list = nullptr; a.ol.cx = a.ol.cy = a.ol.cz = 0.0; a.ol.hmax = 1.0;
     const bool lean = a.nbr && a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv && !a.h_by_id &&
                       a.counters;
     const bool lean2 = a.nbr && a.h_by_id && !a.h_sorted && !a.list64 && !a.idx64 && !a.dist && !a.nontriv &&
@@ -505,23 +726,88 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     // Hinted searches of the step loop and of the device API: the lane-per-query grouped kernel first, then this
     // kernel in list mode for whatever it could not certify (sphx_knn_group.hip).
     if ((lean || lean2) && ctx->use_group && ctx->knn_hinted && rsearch && ctx->exp_knn < 0) {
-        SPHX_TRY(sphx_ensure(ctx, ctx->fail_list, ((size_t)a.npad + 64) * sizeof(int)));
-        int* flist = ctx->fail_list.as<int>();
-        int* fcount = flist + a.npad;
-        HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
-        KnnGroupArgs ga;
-        ga.n = a.n; ga.k = a.k; ga.npad = a.npad; ga.n_active = a.n_active;
-        ga.x = a.x; ga.y = a.y; ga.z = a.z; ga.id = a.id; ga.qorder = a.qorder; ga.cell_start = a.cell_start;
-        ga.g = a.g; ga.rsearch = a.rsearch; ga.hint_by_id = a.hint_by_id; ga.rscale = a.rscale; ga.rbound = a.rbound;
-        ga.nbr = a.nbr; ga.h_sorted = lean ? a.h_sorted : nullptr; ga.h_by_id = lean2 ? a.h_by_id : nullptr;
-        ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
-        SPHX_TRY(sphx_knn_group(ctx, ga));
-        a.qlist = flist; a.qcount = fcount;
-        int lblocks = blocks < KNN_LIST_BLOCKS ? blocks : KNN_LIST_BLOCKS;
-        if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
-        else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ctx->scal.as<u64>() + SC_NFAILQ, fcount, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        const size_t tile_bytes = (size_t)k * (KNN_PPB + 1) * sizeof(int);
+        // What the previous hinted search reported (copied out behind it, on the host long since: no wait): queries it
+        // left to the general kernel, far queries (outside the grid box, wide spheres), radii that contradicted their hints
+        const bool lagged = ctx->olev_mode == 2 || ctx->distrust_mode == 2;
+        if (lagged && ctx->olev_ev_valid) {
+            HIPCHK(hipEventSynchronize(ctx->olev_ev));
+            const u64* v = (const u64*)((const char*)ctx->pinned + 3072);        // slots SC_NFAILQ .. SC_BADHINT
+            const int64_t fb = (int64_t)(u32)v[0];
+            ctx->farq_last = (int64_t)(v[2] >= ctx->farq_seen ? v[2] - ctx->farq_seen : v[2]);
+            ctx->farq_seen = v[2];
+            const int64_t bad = (int64_t)(v[3] >= ctx->badhint_seen ? v[3] - ctx->badhint_seen : v[3]);
+            ctx->badhint_seen = v[3];
+            if (ctx->distrust_mode == 2) {
+                if (!ctx->distrust) ctx->distrust = fb * 4 > n;
+                else ctx->distrust = bad * 20 > n;
+            }
+            ctx->olev_ev_valid = false;
+        }
+        if (ctx->distrust_mode != 2) ctx->distrust = ctx->distrust_mode == 1;
+        // Outlier levels: built when that search met many far queries - a diverging run's escapers, an expanding cloud's rim
+        // ... or when the true bounding box the grid build knew reaches far beyond the grid box
+        double excess = 0.0;
+        {
+            const GridParams& g = ctx->grid;
+            const double lo[3] = {g.xmin, g.ymin, g.zmin}, hi[3] = {g.xmin + g.nx * g.cell, g.ymin + g.ny * g.cell, g.zmin + g.nz * g.cell};
+            for (int c = 0; c < 3; ++c) {
+                const double e0 = (lo[c] - ctx->tbox_h[c]) * g.inv_cell, e1 = (ctx->tbox_h[3 + c] - hi[c]) * g.inv_cell;
+                if (e0 > excess) excess = e0;
+                if (e1 > excess) excess = e1;
+            }
+        }
+        const bool levels = ctx->olev_mode == 1 || (ctx->olev_mode == 2 && (ctx->farq_last >= 256 || excess > 64.0));
+        a.ol.L = 0;
+        if (levels) {
+            SPHX_TRY(sphx_build_outlier_levels(ctx, n, xs, ys, zs));
+            a.ol = ctx->olev;
+        }
+        ctx->stats.far_queries = ctx->farq_last;
+        ctx->stats.outlier_levels = a.ol.L;
+        if (ctx->distrust) {
+            // every query by the general kernel, radii seeded from the cell counts (the hint is one rung of the ladder)
+            a.distrust = 1;
+            if (a.ol.L > 0) {
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 0, 1>), dim3(blocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2, 0, 1>), dim3(blocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+            } else {
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2>), dim3(blocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_NFAILQ, 0, sizeof(u64), ctx->stream));
+        } else {
+            SPHX_TRY(sphx_ensure(ctx, ctx->fail_list, ((size_t)a.npad + 64) * sizeof(int)));
+            int* flist = ctx->fail_list.as<int>();
+            int* fcount = flist + a.npad;
+            HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
+            KnnGroupArgs ga;
+            ga.n = a.n; ga.k = a.k; ga.npad = a.npad; ga.n_active = a.n_active;
+            ga.x = a.x; ga.y = a.y; ga.z = a.z; ga.id = a.id; ga.qorder = a.qorder; ga.cell_start = a.cell_start;
+            ga.g = a.g; ga.rsearch = a.rsearch; ga.hint_by_id = a.hint_by_id; ga.rscale = a.rscale; ga.rbound = a.rbound;
+            ga.nbr = a.nbr; ga.h_sorted = lean ? a.h_sorted : nullptr; ga.h_by_id = lean2 ? a.h_by_id : nullptr;
+            ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
+            SPHX_TRY(sphx_knn_group(ctx, ga));
+            a.qlist = flist; a.qcount = fcount;
+            int lblocks = blocks < KNN_LIST_BLOCKS ? blocks : KNN_LIST_BLOCKS;
+            if (a.ol.L > 0) {
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+            } else {
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(ctx->scal.as<u64>() + SC_NFAILQ, fcount, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (lagged) {
+            if (!ctx->olev_ev) HIPCHK(hipEventCreateWithFlags(&ctx->olev_ev, hipEventDisableTiming));
+            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 3072, ctx->scal.as<u64>() + SC_NFAILQ, 4 * sizeof(u64), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+            HIPCHK(hipEventRecord(ctx->olev_ev, ctx->stream));
+            ctx->olev_ev_valid = true;
+        }
         return SPHX_OK;
     }
     if (lean) hipLaunchKernelGGL((knn_kernel<0, 1>), dim3(blocks), dim3(KNN_BLOCK), (size_t)k * (KNN_PPB + 1) * sizeof(int), ctx->stream, a);

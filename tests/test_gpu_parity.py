@@ -798,7 +798,10 @@ def test_grouped_search_equals_general_search(workload, n, K, steps, kw, monkeyp
     s0 = ics.WORKLOADS[workload](n)
     fixed_dt = ics.cfl_dt(s0, K) if workload == "sedov" else 0.0
     res, fb = {}, {}
-    for name, env in (("grouped", {}), ("general", {"SPHX_KNN_GROUP": "0"}), ("grouped_morton", {"SPHX_BLOB_CURVE": "1"})):
+    for name, env in (("grouped", {}), ("general", {"SPHX_KNN_GROUP": "0"}), ("grouped_morton", {"SPHX_BLOB_CURVE": "1"}),
+                      ("levels_on", {"SPHX_OUTLIER_LEVELS": "1"}), ("levels_off", {"SPHX_OUTLIER_LEVELS": "0"}),
+                      ("distrust", {"SPHX_HINT_DISTRUST": "1"}), ("distrust_levels", {"SPHX_HINT_DISTRUST": "1", "SPHX_OUTLIER_LEVELS": "1"}),
+                      ("trusting", {"SPHX_HINT_DISTRUST": "0"})):
         for k_, v in env.items():
             monkeypatch.setenv(k_, v)
         sim = Simulation(s0, n_neigh=K, **kw)
@@ -811,6 +814,44 @@ def test_grouped_search_equals_general_search(workload, n, K, steps, kw, monkeyp
     if workload == "polytrope":
         assert 0 < fb["grouped"] < 0.1 * n          # the grouped kernel really did certify nearly all of them
         assert sim.stats()["short_rows"] == 0       # no search gave up with a short row (sphx_stats.short_rows)
-    for name in ("general", "grouped_morton"):
+    for name in ("general", "grouped_morton", "levels_on", "levels_off", "distrust", "distrust_levels", "trusting"):
         for key in ("points", "velocities", "E_internal", "T", "sizes", "densities", "total_accel"):
             assert np.array_equal(res["grouped"][key], res[name][key], equal_nan=True), (name, key)
+
+
+@pytest.mark.parametrize("levels,distrust", [("1", "2"), ("2", "2"), ("0", "2"), ("1", "1"), ("0", "1")])
+def test_search_with_outlier_levels_is_exact_on_a_heavy_tailed_cloud(levels, distrust, monkeypatch):
+    """A compact core with a halo of escapers spread over five decades in radius - what the reference's scheme leaves behind
+    when it diverges.  The halo's queries lie outside the grid box with search spheres hundreds of cells
+    wide; with the outlier levels (SPHX_OUTLIER_LEVELS=1: always, 2: the default - built when the cloud's bounding box
+    reaches far beyond the grid box or the previous search met 256 such queries) they walk nested coarse grids over the
+    outliers and the grid with the outliers filtered out; SPHX_HINT_DISTRUST=1 sends every query to the general kernel
+    with its radius seeded from the cell counts (what a diverged run switches to by itself).  Every radius must equal the
+    exact K-th-neighbour distance (cKDTree, eps = 0) - a lost or doubled candidate would change it - on every step."""
+    from sph_code_amd.sim import Simulation
+    import sph_code_amd.ics as ics
+    n_core, n_halo, K = 40000, 6000, 40
+    rs = np.random.RandomState(77)
+    s0 = ics.WORKLOADS["uniform_cube"](n_core + n_halo)
+    core = (rs.rand(n_core, 3) - 0.5) * 2e17
+    u = rs.normal(size=(n_halo, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    halo = u * (10.0 ** rs.uniform(17.2, 21.8, n_halo))[:, None]
+    halo[:50] *= np.array([1.0, 1e-3, 1e-3])                         # a few along one axis: elongated reach
+    s0["points"] = np.ascontiguousarray(np.concatenate([core, halo]))
+    s0["velocities"] = np.zeros_like(s0["points"])
+    monkeypatch.setenv("SPHX_OUTLIER_LEVELS", levels)
+    monkeypatch.setenv("SPHX_HINT_DISTRUST", distrust)        # "1": no grouped kernel, every radius seeded from the cell counts
+    from oracle import sph_oracle as orc
+    sim = Simulation(s0, n_neigh=K)
+    pts = s0["points"]
+    for it in range(3):
+        _, _, _, _, h_ref = orc.neighbors(pts, np.inf, K, eps=0.0)
+        sim.step(1, fixed_dt=1e-30)                                    # (next to nothing moves: the same cloud, searched thrice)
+        d = sim.download()
+        assert np.array_equal(d["sizes"], h_ref), (it, np.abs(d["sizes"] - h_ref).max())
+        st = sim.stats()
+        assert st["short_rows"] == 0
+        assert (st["outlier_levels"] > 0) == (levels != "0" and it >= 1), (it, st)     # (step 0 has no hints: plain search)
+        pts = d["points"]
+        assert np.isfinite(pts).all()

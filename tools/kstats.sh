@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ks -- \
     python3 "$ROOT/bench.py" --no-cpu --steps 20 --warmup 3 "$@" > "$OUT/run.log" 2>&1
-tail -1 "$OUT/run.log" > "$ROOT/gpurun_out/${PREFIX}_bench.json"
+grep '^{' "$OUT/run.log" | tail -1 > "$ROOT/gpurun_out/${PREFIX}_bench.json"
 f=$(find "$OUT" -name '*kernel_stats.csv' | head -1)
 cp "$f" "$ROOT/gpurun_out/${PREFIX}_kernel_stats.csv"
 python3 - "$f" <<'PY'
