@@ -202,7 +202,8 @@ def main():
                          "ms_integrate", "ms_gravity", "ms_total")},
         "search": {"candidates_per_particle_step": st["candidates"] / max(st["steps"], 1) / args.n,
                    "retries_per_step": st["retries"] / max(st["steps"], 1), "cells": st["cells"],
-                   "fallback_queries_last_step": st.get("fallback_queries", 0), "short_rows": st.get("short_rows", 0),
+                   "fallback_queries_last_step": st.get("fallback_queries", 0), "short_rows": st.get("short_rows", 0), "far_queries": st.get("far_queries", 0),
+                   "outlier_levels": st.get("outlier_levels", 0),
                    "refresh_steps": st["refresh_steps"], "rebuild_steps": st["rebuild_steps"]},
     }
     if not args.no_cpu:

@@ -166,13 +166,14 @@ struct sphx_ctx {
     bool olev_ev_valid = false;
     u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
     int64_t farq_last = 0;          // far queries met by the previous hinted search
-    // hint distrust: when the previous hinted search left more than a quarter of its queries to the general kernel (a
-    // diverging run: particles move by several h per step, the previous radii say nothing) the next ones skip the
-    // grouped kernel and seed every radius from the local cell counts; back to normal once the radii found agree with
-    // the hints again (fewer than 5 % beyond [0.5, 1.5] x hint)
+    // hint distrust (an experiment kept as an option, off by default): skip the grouped kernel and seed every radius
+    // from the local cell counts.  Auto mode enters when the previous hinted search left more than a quarter of its
+    // queries to the general kernel (a diverging run: particles move by several h per step) and leaves once fewer than
+    // 5 % of the radii found lie beyond [0.5, 1.5] x hint.  Measured on the diverged cube: no faster than the grouped
+    // kernel certifying what it can and the list-mode kernel re-seeding the stale hints it meets.
     bool distrust = false;
     u64 badhint_seen = 0;
-    int distrust_mode = 2;          // SPHX_HINT_DISTRUST: 0 never, 1 always, 2 auto
+    int distrust_mode = 0;          // SPHX_HINT_DISTRUST: 0 never, 1 always, 2 auto
     int blob_curve = 0;             // 0: Hilbert where its code space fits, 1: Morton always (SPHX_BLOB_CURVE)
     // sphx_blob.hip: per-workgroup distinct-neighbour lists + 16-bit slot lists for the LDS passes
     DevBuf slot16, uniq;
