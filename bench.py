@@ -188,7 +188,8 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": prof.get("traffic_bytes_per_launch"),
                      "traffic_source": prof.get("source", None),
-                     "limiter": "VALU issue + LDS/memory latency (L2 hit rate ~98 %; not HBM)",
+                     "limiter": "VALU issue (instruction count) + LDS/memory latency; not HBM",
+                     "l2_hit_rate": prof.get("l2_hit_rate"),
                      "valu_issue_frac": prof.get("valu_issue_frac"),
                      "valu_wave_instr_per_query": prof.get("valu_wave_instr_per_query"),
                      "profiled_counters_source": prof.get("source", None),

@@ -9,7 +9,8 @@ pmc = json.load(open("gpurun_out/%s_pmc_per_launch.json" % prefix))
 ks = {r["Name"]: r for r in csv.DictReader(open("gpurun_out/%s_kernel_stats.csv" % prefix))}
 def avg_us(sub):
     return [float(r["AverageNs"]) / 1e3 for nme, r in ks.items() if sub in nme][0]
-grp, lst = pmc["knn_group_kernel"], pmc["knn_kernel<0, 1, 1>"]
+grp = pmc["knn_group_kernel"]
+lst = [v for nme, v in pmc.items() if nme.startswith("knn_kernel<0, 1, 1")][0]      # list mode (LIST = 1)
 traffic = sum((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 for c in (grp, lst))
 cycles = grp["GRBM_GUI_ACTIVE"] / 8.0                       # per XCD
 out = {
@@ -20,7 +21,7 @@ out = {
     "valu_wave_instr_per_query": (grp["SQ_INSTS_VALU"] + lst["SQ_INSTS_VALU"]) / n,
     "l2_hit_rate": grp["TCC_HIT_sum"] / (grp["TCC_HIT_sum"] + grp["TCC_MISS_sum"]),
     "wave_wait_frac": grp["SQ_WAIT_ANY"] / grp["SQ_WAVE_CYCLES"],
-    "kernel_us": {"knn_group_kernel": avg_us("knn_group_kernel"), "knn_kernel<0,1,1>": avg_us("knn_kernel<0, 1, 1>")},
+    "kernel_us": {"knn_group_kernel": avg_us("knn_group_kernel"), "knn_kernel<0,1,1>": avg_us("knn_kernel<0, 1, 1")},
 }
 json.dump(out, open("profiles/latest_search_profile.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
