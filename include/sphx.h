@@ -388,6 +388,13 @@ int sphx_dev_species(sphx_ctx* ctx, int nspecies, const double* f_un, const doub
  * reach an owned particle claims (h, w (n), vel (n,3): device).                                          */
 int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
                    double skin_frac, double dt_last, double* w);
+/* the same with dt read from device memory (as sphx_dev_integrate_auto / _loop left it), and the send mask of a plan:
+   mask[p][i] = 1 when rank p's need map (maps: (world, G^3) bytes) covers the coarse cell of owned particle i (p != rank),
+   counts[p] = how many.  Both let DistributedSim plan the NEXT step's halo before the host has read this step's scalars. */
+int sphx_dev_reach_dt(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
+                      double skin_frac, const double* dt_dev, double* w);
+int sphx_dev_plan_mask(sphx_ctx* ctx, int64_t n, const double* pos, const double* g_lo, double g_cs, int G,
+                       int world, int rank, const unsigned char* maps, unsigned char* mask, int64_t* counts);
 /* multigpu.py DistributedSim.step, this rank's end-of-step scalars in one launch: out4 (device) =
  * { any(h_i + 2 D > w_i) ? 1 : 0,  -(*ct) (ct NULL: untouched),  max h,  mean of the h <= hclip (hclip <= 0: all) }
  * over the n_owned first entries of h and w_plan.                                                        */

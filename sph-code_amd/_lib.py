@@ -92,6 +92,8 @@ SIGNATURES = {
     "sphx_dev_need_map": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_double), C.c_double, C.c_int, _P]),
     "sphx_dev_integrate_auto": (C.c_int, [_P, C.c_int64] + [_P] * 13 + [C.c_int, C.c_double, _P]),
     "sphx_dev_reach": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
+    "sphx_dev_reach_dt": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
+    "sphx_dev_plan_mask": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "sphx_dev_step_scalars": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "sphx_dev_integrate": (C.c_int, [_P, C.c_int64] + [_P] * 12 + [C.c_double]),
     "sphx_dev_drag": (C.c_int, [_P] + [_P] * 6),

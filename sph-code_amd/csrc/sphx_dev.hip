@@ -612,16 +612,29 @@ __global__ __launch_bounds__(256) void need_map_kernel(long long n, const double
     const double ty = fmin(fmax(floor((pos[3 * i + 1] - ly) / cs), 0.0), g1);
     const double tz = fmin(fmax(floor((pos[3 * i + 2] - lz) / cs), 0.0), g1);
     const int cx = (tx == tx) ? (int)tx : 0, cy = (ty == ty) ? (int)ty : 0, cz = (tz == tz) ? (int)tz : 0;
-    const double rr = floor(wi / cs) + 1.0;
+    const double q = wi / cs;
+    const double rr = floor(q) + 1.0;
     const int r = rr < (double)G ? (int)rr : G;
+    const double q2 = q * q;                       // (inf for an overflowing reach: everything is claimed)
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
     const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
-    for (int z = z0; z <= z1; ++z)
+    // a SPHERE of cells, not the cube around it (whose corners reach 1.7 x as far - into the dense cloud, for the
+    // wide claims of rim particles): a cell d = (dx, dy, dz) cells away can hold a point within w only if
+    // sum_a max(|d_a| - 1, 0)^2 <= (w / cell)^2  (integers against one double: the tensor-library form does the same)
+    for (int z = z0; z <= z1; ++z) {
+        const int az = max(abs(z - cz) - 1, 0);
         for (int y = y0; y <= y1; ++y) {
+            const int ay = max(abs(y - cy) - 1, 0);
+            const int s2 = az * az + ay * ay;
+            if (!((double)s2 <= q2)) continue;
             unsigned char* row = out + ((size_t)z * G + y) * G;
-            for (int x = x0; x <= x1; ++x) row[x] = 1;
+            for (int x = x0; x <= x1; ++x) {
+                const int ax = max(abs(x - cx) - 1, 0);
+                if ((double)(s2 + ax * ax) <= q2) row[x] = 1;
+            }
         }
+    }
 }
 
 extern "C" int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
@@ -661,6 +674,80 @@ extern "C" int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const d
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(reach_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, h, vel,
                        halo_scale, skin_frac, dt_last, w);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// the same with dt read from device memory (the step's dt as sphx_dev_integrate_auto left it): the next step's plan is
+// made before the host has seen this step's scalars
+__global__ __launch_bounds__(256) void reach_dt_kernel(long long n, const double* h, const double* vel, double halo,
+                                                       double skin, const double* dt_dev, double* w) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dt = *dt_dev;
+    const double vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+    const double speed = sqrt((vx * vx + vy * vy) + vz * vz);
+    const double hi = h[i];
+    w[i] = fmax((halo + skin) * hi, halo * hi + speed * dt);
+}
+extern "C" int sphx_dev_reach_dt(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
+                                 double skin_frac, const double* dt_dev, double* w) {
+    if (!ctx) return SPHX_E_ARG;
+    if (n < 0) return sphx_set_err(ctx, SPHX_E_ARG, "n=%lld", (long long)n);
+    if (n == 0) return SPHX_OK;
+    NEED(h); NEED(vel); NEED(w); NEED(dt_dev);
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(reach_dt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, h, vel,
+                       halo_scale, skin_frac, dt_dev, w);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+// Who gets which owned particle as a ghost (DistributedSim._plan): mask[p][i] = 1 when rank p's need map covers the
+// coarse cell of particle i (p != rank), counts[p] = how many - one launch instead of the tensor-library chain (cell
+// ids, a W x n gather, compare, sum).  The cell is the one need_map_kernel gives the particle.
+__global__ __launch_bounds__(256) void plan_mask_kernel(long long n, const double* pos, double lx, double ly, double lz,
+                                                        double cs, int G, int W, int rank, const unsigned char* maps,
+                                                        unsigned char* mask, long long* counts) {
+    __shared__ int wsum[4];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t cell = 0;
+    if (i < n) {
+        const double g1 = (double)(G - 1);
+        const double tx = fmin(fmax(floor((pos[3 * i] - lx) / cs), 0.0), g1);
+        const double ty = fmin(fmax(floor((pos[3 * i + 1] - ly) / cs), 0.0), g1);
+        const double tz = fmin(fmax(floor((pos[3 * i + 2] - lz) / cs), 0.0), g1);
+        const int cx = (tx == tx) ? (int)tx : 0, cy = (ty == ty) ? (int)ty : 0, cz = (tz == tz) ? (int)tz : 0;
+        cell = ((size_t)cz * G + cy) * G + cx;
+    }
+    const size_t G3 = (size_t)G * G * G;
+    for (int p = 0; p < W; ++p) {
+        unsigned char m = 0;
+        if (i < n && p != rank) m = maps[(size_t)p * G3 + cell] != 0 ? 1 : 0;
+        if (i < n) mask[(size_t)p * n + i] = m;
+        const int c = __popcll(__builtin_amdgcn_ballot_w64(m != 0));
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (t) atomicAdd((unsigned long long*)&counts[p], (unsigned long long)t);
+        }
+        __syncthreads();
+    }
+}
+extern "C" int sphx_dev_plan_mask(sphx_ctx* ctx, int64_t n, const double* pos, const double* g_lo, double g_cs, int G,
+                                  int world, int rank, const unsigned char* maps, unsigned char* mask, int64_t* counts) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(g_lo); NEED(counts);
+    if (n < 0 || G < 1 || G > 1024 || !(g_cs > 0.0) || world < 1 || world > 4096 || rank < 0 || rank >= world)
+        return sphx_set_err(ctx, SPHX_E_ARG, "plan mask: n=%lld G=%d cs=%g world=%d rank=%d", (long long)n, G, g_cs, world, rank);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(counts, 0, (size_t)world * sizeof(int64_t), ctx->stream));
+    if (n == 0) return SPHX_OK;
+    NEED(pos); NEED(maps); NEED(mask);
+    hipLaunchKernelGGL(plan_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, pos,
+                       g_lo[0], g_lo[1], g_lo[2], g_cs, G, world, rank, maps, mask, (long long*)counts);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -33,6 +33,7 @@ libsphx.so's sphx_dev_* entry points on the rank's GPU (no CPU fallback).
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -122,14 +123,16 @@ class Exchanger:
             if p is not None and float(r[0]) != float(p):
                 raise RuntimeError("halo warm-up: rank %d got %r from rank %d" % (self.rank, float(r[0]), p))
 
-    def rows(self, send_bufs, recv_counts, width, dtype=torch.float64, into=None):
+    def rows(self, send_bufs, recv_counts, width, dtype=torch.float64, into=None, defer=False):
         """send_bufs[p]: (count_p, width) tensor for peer p (any device) -> list of received
         (recv_counts[p], width) tensors on the compute device of send_bufs.  `into`: a contiguous
         (sum(recv_counts), width) tensor on the communication device; peers' rows are then received
-        straight into its consecutive slices (which the returned list aliases)."""
+        straight into its consecutive slices (which the returned list aliases).  defer=True: the transfers are
+        started and a function is returned that completes them (and gives the list): what the caller launches in
+        between runs beside the exchange (RCCL moves the rows on its own stream; wait() orders the streams)."""
         out = [None] * self.world
         if self.world == 1:
-            return out
+            return (lambda: out) if defer else out
         ops, stage = [], []
         dev = None
         o = 0
@@ -151,13 +154,17 @@ class Exchanger:
                     r = torch.empty((recv_counts[p], width), dtype=dtype, device=self.comm_device)
                 ops.append(dist.P2POp(dist.irecv, r, p))
                 out[p] = r
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops) if ops else []
+
+        def finish():
+            for w in works:
                 w.wait()
-        for p in range(self.world):
-            if out[p] is not None and dev is not None and out[p].device != dev:
-                out[p] = out[p].to(dev)
-        return out
+            stage.clear()
+            for p in range(self.world):
+                if out[p] is not None and dev is not None and out[p].device != dev:
+                    out[p] = out[p].to(dev)
+            return out
+        return finish if defer else finish()
 
 
 # ==============================================================================================
@@ -231,6 +238,24 @@ class LibBackend:
         self._chk(self.lib.sphx_dev_reach(self.ctx.h, int(h.shape[0]), self._p(h.contiguous()), self._p(vel.contiguous()),
                                           float(halo_scale), float(skin_frac), float(dt_last), self._p(w)))
         return w
+
+    def reach_dt(self, h, vel, halo_scale, skin_frac, dt_dev):
+        """sphx_dev_reach with dt taken from device memory (the (1,) tensor sphx_dev_integrate_auto / _loop filled)."""
+        w = torch.empty_like(h)
+        self._chk(self.lib.sphx_dev_reach_dt(self.ctx.h, int(h.shape[0]), self._p(h.contiguous()), self._p(vel.contiguous()),
+                                             float(halo_scale), float(skin_frac), self._p(dt_dev), self._p(w)))
+        return w
+
+    def plan_mask(self, pos, g_lo, g_cs, G, maps, rank):
+        """(mask (W, n) uint8, counts (W,) int64): which owned particle goes to which peer as a ghost, and how many, from
+        the ranks' need maps (W, G^3) - one launch (sphx_dev_plan_mask)."""
+        W, n = int(maps.shape[0]), int(pos.shape[0])
+        mask = torch.empty((W, n), dtype=torch.uint8, device=self.device)
+        counts = torch.empty(W, dtype=torch.int64, device=self.device)
+        lo = (C.c_double * 3)(*g_lo)
+        self._chk(self.lib.sphx_dev_plan_mask(self.ctx.h, n, self._p(pos.contiguous()), lo, float(g_cs), int(G), W, int(rank),
+                                              self._p(maps.contiguous()), self._p(mask), self._p(counts)))
+        return mask, counts
 
     def step_scalars(self, n_owned, h, w_plan, D, hclip, ct):
         """(4,) device tensor {halo too thin?, -crossing time, max h, clipped mean h} in one launch
@@ -450,6 +475,9 @@ class DistributedSim:
         # when the plan went stale on three steps running (large dt: some particle always moves more
         # than the skin), the next steps replan without asking - two host-synchronising reductions less
         self.stale_streak, self.force_replan = 0, 0
+        self._nonzero_static = None       # torch.nonzero_static usable on this device? (found out at the first plan)
+        self.plan_next = None             # the NEXT step's plan, made at the end of this one (see step)
+        self.plan_ahead = True
         # coarse global grid for the need maps: global bounding box of the initial state + 25 %
         pmin = self.s["pos"].min(dim=0).values if n else torch.full((3,), 1e300, dtype=torch.float64, device=self.device)
         pmax = self.s["pos"].max(dim=0).values if n else torch.full((3,), -1e300, dtype=torch.float64, device=self.device)
@@ -520,43 +548,94 @@ class DistributedSim:
         return (c[:, 2] * self.G + c[:, 1]) * self.G + c[:, 0]
 
     def _need_map(self, w_owned):
-        """uint8 (G^3,): coarse cells from which a particle could lie within w_i of one of my owned
-        particles.  Conservative: distances are under-estimated (Chebyshev cell distance - 1)."""
+        """uint8 (G^3,): coarse cells from which a particle could lie within w_i of one of my owned particles.  A cell
+        d = (dx, dy, dz) cells away from an owned particle's cell is marked when sum_a max(|d_a| - 1, 0)^2 <= (w_i / cell)^2:
+        a sphere of cells (distances under-estimated by one cell per axis), not the cube around it - the wide claims of
+        rim particles would otherwise pull in the dense cloud at the cube's corners."""
         G, cs = self.G, self.g_cs
         if hasattr(self.backend, "need_map"):          # fused: one launch, no host synchronisation
             return self.backend.need_map(self.s["pos"], w_owned, self.g_lo_host, cs, G)
-        wmax = torch.zeros(G * G * G, dtype=torch.float64, device=self.device)
-        if w_owned.numel():
-            wmax.scatter_reduce_(0, self._coarse_cell(self.s["pos"]), w_owned, reduce="amax", include_self=True)
-        reach = torch.where(wmax > 0, wmax + cs * 1.000001, wmax).view(1, 1, G, G, G)
-        iters = int(float(wmax.max()) / cs) + 2 if w_owned.numel() else 0
-        for _ in range(min(iters, G)):
-            reach = torch.maximum(reach, torch.nn.functional.max_pool3d(reach, 3, stride=1, padding=1) - cs)
-        return (reach.view(-1) > 0).to(torch.uint8)
+        # the tensor-library form (the specification: what the CPU tests run, what the kernel is tested against).  The
+        # rule is monotone in w, so a cell's widest claim stands for all its particles; cells are handled per integer
+        # radius class, each against its stencil of offsets.
+        dev = self.device
+        out = torch.zeros(G * G * G, dtype=torch.uint8, device=dev)
+        if not w_owned.numel():
+            return out
+        wmax = torch.zeros(G * G * G, dtype=torch.float64, device=dev)
+        wmax.scatter_reduce_(0, self._coarse_cell(self.s["pos"]), w_owned, reduce="amax", include_self=True)
+        occ = torch.nonzero(wmax > 0).flatten()
+        if not occ.numel():
+            return out
+        q = wmax[occ] / cs
+        r = torch.clamp(torch.floor(q) + 1.0, max=float(G)).to(torch.int64)
+        q2 = q * q
+        cz, cy, cx = occ // (G * G), (occ // G) % G, occ % G
+        for rv in torch.unique(r).tolist():
+            sel = torch.nonzero(r == rv).flatten()
+            lo_r = max(-rv, -(G - 1)); hi_r = min(rv, G - 1)
+            o1 = torch.arange(lo_r, hi_r + 1, device=dev, dtype=torch.int64)
+            a1 = torch.clamp(o1.abs() - 1, min=0)
+            # stencil of this radius class: offsets and their under-estimated squared distance in cells
+            dz, dy, dx = torch.meshgrid(o1, o1, o1, indexing="ij")
+            s2 = (a1 * a1)[:, None, None] + (a1 * a1)[None, :, None] + (a1 * a1)[None, None, :]
+            dz, dy, dx, s2 = dz.reshape(-1), dy.reshape(-1), dx.reshape(-1), s2.reshape(-1).to(torch.float64)
+            chunk = max(1, int(4_000_000 // max(int(s2.numel()), 1)))
+            for c0 in range(0, int(sel.numel()), chunk):
+                ss = sel[c0:c0 + chunk]
+                hit = s2[None, :] <= q2[ss][:, None]                                  # (cells, offsets)
+                z = cz[ss][:, None] + dz[None, :]; y = cy[ss][:, None] + dy[None, :]; x = cx[ss][:, None] + dx[None, :]
+                hit &= (z >= 0) & (z < G) & (y >= 0) & (y < G) & (x >= 0) & (x < G)
+                out[((z * G + y) * G + x)[hit]] = 1
+        return out
 
-    def _plan(self, w_owned):
-        """Send lists from the ranks' need maps (one all_gather of G^3 bytes per rank)."""
+    def _plan_launch(self, w_owned):
+        """Device work and collectives of a plan (one all_gather of G^3 bytes per rank, one of W counts): -> (mask (W, n),
+        both (2, W) int64 on the communication device: what I send to / receive from every peer).  No host read."""
         W = self.world
         mine = self._need_map(w_owned).to(self.comm_device)
         maps = [torch.zeros_like(mine) for _ in range(W)]
         dist.all_gather(maps, mine)
         maps = torch.stack(maps).to(self.device)                              # (W, G^3)
-        cell = self._coarse_cell(self.s["pos"])
-        mask = maps[:, cell] != 0                                             # (W, n)
-        mask[self.rank] = False
-        # counts to every peer, exchanged while still on the device: one host read at the end serves both the
+        if hasattr(self.backend, "plan_mask"):
+            mask, cnt = self.backend.plan_mask(self.s["pos"], self.g_lo_host, self.g_cs, self.G, maps, self.rank)
+        else:
+            cell = self._coarse_cell(self.s["pos"])
+            mask = maps[:, cell] != 0                                         # (W, n)
+            mask[self.rank] = False
+            cnt = mask.sum(dim=1)
+        # counts to every peer, exchanged while still on the device: ONE host read (the caller's) serves both the
         # send lists and what the peers will send (each read drains the stream)
-        cnt = mask.sum(dim=1).to(self.comm_device)                            # (W,) int64
+        cnt = cnt.to(self.comm_device)                                        # (W,) int64
         allc = [torch.zeros_like(cnt) for _ in range(W)]
         dist.all_gather(allc, cnt)
-        pk = torch.nonzero(mask)                                              # sorted by peer, then particle
-        both = torch.stack([cnt, torch.stack(allc)[:, self.rank]]).tolist()
-        counts, recv_counts = both[0], both[1]
+        return mask, torch.stack([cnt, torch.stack(allc)[:, self.rank]])
+
+    def _plan_finish(self, mask, both):
+        """Send lists from the mask, now that the host knows the counts (`both` as nested lists)."""
+        counts, recv_counts = [int(v) for v in both[0]], [int(v) for v in both[1]]
+        total = sum(counts)
+        pk = None
+        if self._nonzero_static is not False:                                 # sized by the counts: no second host read
+            try:
+                pk = torch.nonzero_static(mask, size=total)
+                self._nonzero_static = True
+            except (RuntimeError, NotImplementedError, AttributeError):
+                if self._nonzero_static:
+                    raise
+                self._nonzero_static = False
+        if pk is None:
+            pk = torch.nonzero(mask)                                          # sorted by peer, then particle
         send_idx, o = [], 0
-        for p in range(W):
+        for p in range(self.world):
             send_idx.append(None if p == self.rank else pk[o:o + counts[p], 1].contiguous())
             o += counts[p]
         return send_idx, recv_counts
+
+    def _plan(self, w_owned):
+        """Send lists from the ranks' need maps."""
+        mask, both = self._plan_launch(w_owned)
+        return self._plan_finish(mask, both.tolist())
 
     # rows <-> separate arrays.  Backends with fused kernels (LibBackend) do each in one launch; the
     # tensor-library forms below are the specification (and what the CPU tests run).
@@ -590,14 +669,16 @@ class DistributedSim:
                 c += w
         return [o.view(torch.int64) if d == torch.int64 else o for o, d in zip(outs, dts)]
 
-    def _exchange(self, send_idx, recv_counts, fields, into=None, send_cat=None):
+    def _exchange(self, send_idx, recv_counts, fields, into=None, send_cat=None, defer=False):
         """Rows of `fields` for every peer's send list -> the received rows (n_recv, W), ordered by
-        source rank.  `into`: receive in place (a contiguous (n_recv, W) view on the compute device)."""
+        source rank.  `into`: receive in place (a contiguous (n_recv, W) view on the compute device).
+        defer=True: started only; the returned function completes the exchange and gives the rows."""
         W = sum(1 if f.dim() == 1 else f.shape[1] for f in fields)
         dev = fields[0].device
         nrecv = sum(recv_counts)
         if self.world == 1:
-            return into if into is not None else torch.zeros((0, W), dtype=torch.float64, device=dev)
+            res1 = into if into is not None else torch.zeros((0, W), dtype=torch.float64, device=dev)
+            return (lambda: res1) if defer else res1
         if send_cat is None:
             parts = [ix for ix in send_idx if ix is not None and ix.numel()]
             send_cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
@@ -611,22 +692,29 @@ class DistributedSim:
         if into is None and dev == self.comm_device:
             into = torch.empty((nrecv, W), dtype=torch.float64, device=dev)
             direct = True
-        got = self.ex.rows(bufs, recv_counts, W, into=into if direct else None)
-        if direct:
-            return into
-        parts = [g for g in got if g is not None]
-        res = torch.cat(parts, dim=0) if parts else torch.zeros((0, W), dtype=torch.float64, device=dev)
-        if into is not None:
-            into.copy_(res)
-            return into
-        return res
+        pending = self.ex.rows(bufs, recv_counts, W, into=into if direct else None, defer=True)
+
+        def finish():
+            got = pending()
+            if direct:
+                return into
+            parts = [g for g in got if g is not None]
+            res = torch.cat(parts, dim=0) if parts else torch.zeros((0, W), dtype=torch.float64, device=dev)
+            if into is not None:
+                into.copy_(res)
+                return into
+            return res
+        return finish if defer else finish()
 
     # ------------------------------------------------------------------------------------------
+    def _migration_due(self):
+        k_ = self.stats.get("replans", 0)
+        return k_ < 2 or k_ % self.migrate_every == 0       # (the first two: one-off set-up costs paid early)
+
     def _replan(self):
         """Migrate strays to their region's owner, then rebuild the send lists: every owned particle
         claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
-        k_ = self.stats.get("replans", 0)
-        if k_ < 2 or k_ % self.migrate_every == 0:        # (the first two: one-off set-up costs paid early)
+        if self._migration_due():
             self._reorder_and_migrate()
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
@@ -714,7 +802,15 @@ class DistributedSim:
             # made now is exact (D = 0); never compare against positions the plan was not made at
             self.force_replan = max(self.force_replan - 1, 0)
             with self._sec("replan"):
-                self._replan()
+                if self.plan_next is not None:
+                    # made at the end of the previous step on the very positions this step starts from (its
+                    # collectives behind that step's sums, its counts in that step's one host read)
+                    self.w_plan, self.send_idx, self.recv_counts, self.send_cat = self.plan_next
+                    self.pos_plan = None
+                    self.stats["replans"] = self.stats.get("replans", 0) + 1
+                else:
+                    self._replan()
+            self.plan_next = None
             D = 0.0
         else:
             with self._sec("stale_check"):
@@ -765,8 +861,10 @@ class DistributedSim:
             tail = lambda a: a[no:].view(ng, 1)
             if loop:
                 with self._sec("sums+halo_scalars"):
-                    self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)    # h_j (nsc:711)
+                    # h_j (nsc:711) travels while the step's records are built (they do not read h)
+                    h_done = self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat, defer=True)
                     be.loop_prep(pos, vel, m, T, mu, gam, ptype, E_all, self.d)
+                    h_done()
                     rho, rhod, nden, delp = be.loop_pass1(h)
                     self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)  # rho_j (nsc:803)
                     va, vh, ct = be.loop_pass2(rho)
@@ -813,6 +911,16 @@ class DistributedSim:
                     dist.all_reduce(red, op=dist.ReduceOp.MAX)
                     red = red.to(h.device)
             auto = fused and hasattr(be, "integrate_auto")
+            # (the same on every rank: the plan's collectives are entered by all or by none)
+            ahead_ok = (self.plan_ahead and self.world > 1 and self.force_replan > 0 and not self._migration_due()
+                        and all(hasattr(be, a_) for a_ in ("reach_dt", "plan_mask", "step_scalars", "integrate_auto")))
+            ahead = None
+            if ahead_ok and not auto:
+                # a rank without owned particles: nothing to send, but the collectives are collective
+                with self._sec("plan_ahead"):
+                    mask_next, both_next = self._plan_launch(torch.zeros(0, **f64))
+                    ahead = (torch.zeros(0, **f64), mask_next)
+                    both_host = both_next.tolist()
             if auto:
                 # the update is launched before the host learns the verdict: the kernel itself leaves the state
                 # alone when the step has to be redone, and works out dt from the reduced crossing time
@@ -824,7 +932,22 @@ class DistributedSim:
                 else:
                     dt_t = be.integrate_auto(no, s["pos"], s["vel"], s["acc"], s["E"], s["T"], s["m"], s["mu"], s["gam"],
                                              s["ptype"], ha, va, vh, red_dev.contiguous(), self.first, fixed_dt)
-                vals = torch.cat([red_dev, loc, dt_t]).tolist()
+                # ---- the NEXT step's plan, while the host still has not looked at this one's scalars: the update is
+                # on its way, so the positions the next step starts from are known to the device.  Reach, need map,
+                # both all_gathers and the send mask are launched now; their counts ride in this step's one host read.
+                # (Speculative: a "redo" verdict leaves the state untouched and this plan is dropped.)
+                if ahead_ok:
+                    with self._sec("plan_ahead"):
+                        be.clamp(s["pos"], s["vel"])            # drv:233-238, early: the next step's own clamp finds nothing to do
+                        w_next = be.reach_dt(h[:no].contiguous(), s["vel"], self.halo_scale, self.skin_frac, dt_t)
+                        mask_next, both_next = self._plan_launch(w_next)
+                        ahead = (w_next, mask_next)
+                if ahead is not None and both_next.device == red_dev.device:
+                    vals = torch.cat([red_dev, loc, dt_t, both_next.reshape(-1).to(torch.float64)]).tolist()
+                    both_host = [vals[5:5 + self.world], vals[5 + self.world:5 + 2 * self.world]]
+                else:
+                    vals = torch.cat([red_dev, loc, dt_t]).tolist()
+                    both_host = both_next.tolist() if ahead is not None else None     # (host-memory halo: already there)
             else:
                 vals = out4.tolist() if (fused and red.data_ptr() == out4.data_ptr()) else torch.cat([red, loc]).tolist()
             if vals[0] < 0.5:
@@ -839,6 +962,13 @@ class DistributedSim:
             D = 0.0
             self.stats["redo"] += 1
         ct_min, self.hmax_prev, self.hmean_prev = -vals[1], vals[2], vals[3]
+        self.plan_next = None
+        if ahead is not None:
+            with self._sec("plan_ahead"):
+                send_idx_n, recv_n = self._plan_finish(ahead[1], both_host)
+                parts = [ix for ix in send_idx_n if ix is not None and ix.numel()]
+                cat_n = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=self.device)
+                self.plan_next = (ahead[0], send_idx_n, recv_n, cat_n)
         if auto:
             dt = vals[4]                                   # (worked out and applied on the device)
         else:
@@ -1079,6 +1209,12 @@ def bench_main(args, rank, local_rank, world):
     chk = torch.stack([torch.sqrt(v2.max()) if v2.numel() else v2.new_zeros(()),
                        (~torch.isfinite(sim.s["pos"])).sum().to(torch.float64)]).to(comm_dev)
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+    if os.environ.get("SPHX_MG_DEBUG") and rank == 0:
+        q = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64, device=sim.w_plan.device)
+        print("[mg debug] coarse cell %.4g; h quantiles %s; claimed reach w quantiles %s; |v| dt quantiles %s; dt %.4g; owned %d ghosts/step %.0f"
+              % (sim.g_cs, torch.quantile(sim.s["h"], q).tolist(), torch.quantile(sim.w_plan, q).tolist(),
+                 (torch.quantile(torch.sqrt((sim.s["vel"] ** 2).sum(dim=1)), q) * sim.dt_last).tolist(), sim.dt_last,
+                 sim.n_owned, sim.stats["ghosts"] / max(args.steps, 1)), file=sys.stderr, flush=True)
     kst = be.ctx.stats()                     # rank 0's kNN launches: HIP events on the stream they ran on
     if rank == 0:
         t = float(tmax[0])

@@ -84,9 +84,15 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update
         kw.update(with_drag=True, with_species=True,
                   agb=agb.splines_from_arrays(g["tx"], g["ty"], g["coeffs"], g["mapto"], float(g["divisor"])))
     sim = mg.DistributedSim(mine, lo, hi, mg.LibBackend(0, k=K), rank, world, device="cuda:0", comm_device="cpu", **kw)
+    if os.environ.get("SPHX_TEST_FORCE_REPLAN"):      # the regime of the reference's dt rule: a new plan every step
+        sim.force_replan = int(os.environ["SPHX_TEST_FORCE_REPLAN"])
+        sim.plan_ahead = os.environ.get("SPHX_TEST_PLAN_AHEAD", "1") != "0"
+    n_ahead = 0
     for _ in range(nsteps):
         sim.step()
+        n_ahead += sim.plan_next is not None
     res = sim.owned_numpy()
+    res["plans_made_ahead"] = np.array(n_ahead)
     if "f_un_neighbor" in res:
         res["f_un_neighbor"] = np.ascontiguousarray(res["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
     res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
@@ -119,6 +125,34 @@ def test_ranks_sharing_one_gpu_match_oracle(world, workload, tmp_path):
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
     assert sum(p["stats"][0] for p in parts) > 0
+
+
+@pytest.mark.parametrize("forms", ["hydro_update", "loop"])
+def test_two_ranks_plan_made_ahead_equals_plan_made_at_step_start(forms, tmp_path, monkeypatch):
+    """Under the reference's dt rule every step needs a new halo plan.  The driver then makes the NEXT step's plan at
+    the end of the current one - reach from the device-side dt (sphx_dev_reach_dt), need map, both all_gathers and the
+    send mask (sphx_dev_plan_mask) launched behind the leapfrog update, the counts folded into the step's one host
+    read - except on the steps that migrate particles.  Same trajectories, bit for bit, as planning at step start."""
+    import sph_code_amd.ics as ics
+    n, nsteps, world = 12000, 7, 2
+    res = {}
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("SPHX_TEST_FORCE_REPLAN", "16")
+        monkeypatch.setenv("SPHX_TEST_PLAN_AHEAD", ahead)
+        out = tmp_path / ("ahead" + ahead)
+        out.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), n, nsteps, "uniform_cube" if forms == "loop" else "polytrope", str(out), forms),
+                 nprocs=world, join=True)
+        parts = [dict(np.load(os.path.join(str(out), "rank%d.npz" % r))) for r in range(world)]
+        order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+        res[ahead] = {k_: np.concatenate([p[k_] for p in parts])[order]
+                      for k_ in ("points", "velocities", "E_internal", "sizes", "densities", "total_accel")}
+        res[ahead]["n_ahead"] = [int(p["plans_made_ahead"]) for p in parts]
+        res[ahead]["replans"] = [int(p["stats"][4]) for p in parts]
+    assert min(res["1"]["n_ahead"]) >= 3 and max(res["0"]["n_ahead"]) == 0      # (migration steps plan at step start)
+    assert res["1"]["replans"] == res["0"]["replans"]
+    for k_ in ("points", "velocities", "E_internal", "sizes", "densities", "total_accel"):
+        assert np.array_equal(res["1"][k_], res["0"][k_]), k_
 
 
 def test_two_ranks_sharing_one_gpu_loop_forms_on_the_reference_ic(tmp_path):
