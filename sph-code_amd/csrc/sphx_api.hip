@@ -85,6 +85,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
     if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
     if (const char* e = getenv("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
@@ -115,7 +116,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
              hipEventCreateWithFlags(&ctx->lag_hev[r], hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->ev_perm_fork, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->ev_perm, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = sphx_ensure(ctx, ctx->scal, SC_NSLOTS * 8) == SPHX_OK &&
                  hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess;
     if (!ok) {
@@ -166,6 +169,8 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     if (ctx->olev_ev) (void)hipEventDestroy(ctx->olev_ev);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_perm_fork) (void)hipEventDestroy(ctx->ev_perm_fork);
+    if (ctx->ev_perm) (void)hipEventDestroy(ctx->ev_perm);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -495,6 +500,11 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                 HIPCHK(hipStreamSynchronize(ctx->stream));
                 hs = (const double*)((char*)ctx->pinned + 256);
             }
+            if (ctx->lag_hvalid[ctx->lag_hslot]) {       // the same copy carries the previous search's counters
+                const u64* sv = (const u64*)hs;           // slots SC_HSUM ..: [5] SC_NFAILQ [6] SC_SHORT [7] SC_FARQ [8] SC_BADHINT
+                for (int q = 0; q < 4; ++q) ctx->knn_lag[q] = sv[(SC_NFAILQ - SC_HSUM) + q];
+                ctx->knn_lag_valid = true;
+            }
             const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
             if (hmean > 0.0 && isfinite(hmean)) {
                 cell_hint = ctx->cell_factor * hmean;
@@ -515,7 +525,8 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             //  deferred member sort has run when perm is used)
             if (blob) SPHX_TRY(sphx_build_blob_order(ctx, n));
         }
-        SPHX_TRY(sphx_permute_state(ctx, n));
+        const bool split_perm = ctx->split_perm && ctx->side_stream && !ctx->use_verlet;
+        SPHX_TRY(sphx_permute_state(ctx, n, split_perm));
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         StateArrays& r = ctx->st;
         KnnOut o;
@@ -531,10 +542,13 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             rs = ctx->rscale_build;          // wider: the list must hold 64 entries to earn its margin
         }
         ctx->knn_hinted = ctx->step_count > 0 && !ctx->use_verlet;     // hprev holds the previous step's radii
+        ctx->knn_lag_external = true;
         const int rc_knn = sphx_knn(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), r.id.as<int>(),
                                     ctx->inv.as<int>(), r.hprev.as<double>(), rs, dist, o);
         ctx->knn_hinted = false;
+        ctx->knn_lag_external = false;
         SPHX_TRY(rc_knn);
+        if (split_perm) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_perm, 0));    // the rest of the state is in place
         if (ctx->use_verlet) {
             SPHX_TRY(sphx_save_list_positions(ctx, n, r.x.as<double>(), r.y.as<double>(), r.z.as<double>()));
             ctx->list_valid = true;
@@ -545,18 +559,29 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     }
     StateArrays& s = ctx->st;
     HIPCHK(hipEventRecord(ev[2], ctx->stream));
-    SPHX_TRY(sphx_hsum(ctx, n, s.hprev.as<double>()));
-    {   // the next step's cell size: out to the host now, read there when the next grid is sized
+    // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side - and with
+    // it the sum of h and its copy to the host (the next step's cell size, read there when the next grid is sized;
+    // the search's counters travel in the same copy: SC_HSUM .. SC_BADHINT are consecutive slots)
+    const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
+    hipStream_t hs_stream = ctx->stream;
+    if (fork) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        hs_stream = ctx->side_stream;
+    }
+    {
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = hs_stream;
+        const int rc_h = sphx_hsum(ctx, n, s.hprev.as<double>());
+        ctx->stream = main_stream;
+        SPHX_TRY(rc_h);
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
-                              4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipEventRecord(ctx->lag_hev[hsl], ctx->stream));
+                              (SC_BADHINT - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
+        HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
         ctx->lag_hvalid[hsl] = true;
         ctx->lag_hslot = hsl;
     }
-    // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side
-    const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
-    if (fork) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
@@ -620,8 +645,9 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                                               ctx->grav.as<double>()));
     }
     HIPCHK(hipEventRecord(ev[8], ctx->stream));
-    SPHX_TRY(sphx_compute_dt(ctx, first, fixed_dt));
-    SPHX_TRY(sphx_integrate(ctx, n));
+    // (dt by drv:222-229 inside the update kernel; the crossing-time vote is reset by the next step's first kernel, or
+    //  primed by its pass 2 when that grid build is not the fused one)
+    SPHX_TRY(sphx_integrate(ctx, n, 1, first, fixed_dt));
     HIPCHK(hipEventRecord(ev[7], ctx->stream));
     ctx->step_count++;
     return SPHX_OK;

@@ -489,7 +489,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         fa.cell_of = ctx->cell_of.as<int>();
         fa.hist = fill;
         fa.partial = part; fa.ticket = ticket; fa.fin = fin;
-        fa.ct_reset = nullptr;
+        fa.ct_reset = ctx->scal.as<u64>() + SC_CT_BITS;      // (read by the previous step's update, long done on this stream)
+        ctx->ct_primed = true;
         int fb = pb < FUSED_MAXBLOCKS ? pb : FUSED_MAXBLOCKS;
         hipLaunchKernelGGL(grid_count_fused, dim3(fb), dim3(RED_BLOCK), 0, ctx->stream, fa);
         hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(256), 0, ctx->stream, fb, part, fin);

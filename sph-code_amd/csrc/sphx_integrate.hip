@@ -45,9 +45,11 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     if (t >= a.n) return;
     const int p = a.perm[t];
     for (int q = 0; q < a.narr; ++q) a.dst[q][t] = a.src[q][p];
-    const int id = a.id_src[p];
-    a.id_dst[t] = id;
-    a.inv[id] = t;
+    if (a.id_src) {
+        const int id = a.id_src[p];
+        a.id_dst[t] = id;
+        a.inv[id] = t;
+    }
     if (a.fun_src) {                       // rows of a.s doubles, a multiple of 16: aligned 16-B copies
         const double2* src = reinterpret_cast<const double2*>(a.fun_src + (size_t)p * a.s);
         double2* dst = reinterpret_cast<double2*>(a.fun_dst + (size_t)t * a.s);
@@ -55,13 +57,17 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     }
 }
 
-int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
+// split = true (the fused loop, a side stream at hand): what the search reads - positions, previous radii, ids - is
+// permuted on the main stream, everything else on the side stream beside the search (which is bound by instruction
+// issue and leaves the memory system idle); the caller makes the main stream wait for ctx->ev_perm before it reads those.
+int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split) {
     StateArrays& a = ctx->st;
     StateArrays& b = ctx->alt;
-    DevBuf* src[] = {&a.x, &a.y, &a.z, &a.vx, &a.vy, &a.vz, &a.ax, &a.ay, &a.az,
-                     &a.m, &a.T, &a.mu, &a.gam, &a.E, &a.hprev, &a.ptype};
-    DevBuf* dst[] = {&b.x, &b.y, &b.z, &b.vx, &b.vy, &b.vz, &b.ax, &b.ay, &b.az,
-                     &b.m, &b.T, &b.mu, &b.gam, &b.E, &b.hprev, &b.ptype};
+    // (the search's arrays first)
+    DevBuf* src[] = {&a.x, &a.y, &a.z, &a.hprev, &a.vx, &a.vy, &a.vz, &a.ax, &a.ay, &a.az,
+                     &a.m, &a.T, &a.mu, &a.gam, &a.E, &a.ptype};
+    DevBuf* dst[] = {&b.x, &b.y, &b.z, &b.hprev, &b.vx, &b.vy, &b.vz, &b.ax, &b.ay, &b.az,
+                     &b.m, &b.T, &b.mu, &b.gam, &b.E, &b.ptype};
     GatherArgs g;
     g.n = (int)n; g.narr = 16; g.s = ctx->sp;
     g.perm = ctx->perm.as<int>();
@@ -85,7 +91,23 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n) {
         SPHX_TRY(sphx_ensure(ctx, b.fun, (size_t)n * ctx->sp * sizeof(double)));
         g.fun_src = a.fun.as<double>(); g.fun_dst = b.fun.as<double>();
     }
+    split = split && ctx->side_stream && ctx->ev_perm_fork && ctx->ev_perm;
+    GatherArgs rest = g;                       // velocities ... ptype (+ drag coefficients, + composition): side stream
+    if (split) {
+        rest.narr = g.narr - 4;
+        for (int q = 0; q < rest.narr; ++q) { rest.src[q] = g.src[q + 4]; rest.dst[q] = g.dst[q + 4]; }
+        rest.id_src = nullptr;
+        g.narr = 4;
+        g.fun_src = nullptr; g.fun_dst = nullptr;
+    }
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g);
+    if (split) {
+        // (behind the search's part, not beside it: both are bound by the same memory system)
+        HIPCHK(hipEventRecord(ctx->ev_perm_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_perm_fork, 0));
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->side_stream, rest);
+        HIPCHK(hipEventRecord(ctx->ev_perm, ctx->side_stream));
+    }
     HIPCHK(hipGetLastError());
     StateArrays tmp = ctx->st; ctx->st = ctx->alt; ctx->alt = tmp;
     return SPHX_OK;
@@ -195,11 +217,29 @@ struct IntegArgs {
     const double* dt;
     double m_h, kB;
     int no_old;                                        // drv:484-485: no previous acceleration of this shape
+    // the fused loop: dt worked out here from the step's crossing-time vote (drv:222-229; was a launch of its own) and
+    // left in *dt_out by the first thread; the vote is reset by the next step's first kernel (grid_count_fused)
+    const u64* ct_bits;                                // nullptr: dt is read from *dt
+    double* dt_out;
+    int first;
+    double fixed_dt, dt_0, max_age;
 };
 __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const double dt = *a.dt;
+    double dt;
+    if (a.ct_bits) {
+        if (a.fixed_dt > 0.0) {
+            dt = a.fixed_dt;
+        } else {
+            const u64 b = *a.ct_bits;
+            const double ct = sphx_ct_value(b == SPHX_CT_NONE, __longlong_as_double((long long)b), a.dt_0);   // nsc:783-786
+            dt = sphx_dt_rule(ct, a.first, a.dt_0, a.max_age);                                                  // drv:223-229
+        }
+        if (i == 0) *a.dt_out = dt;
+    } else {
+        dt = *a.dt;
+    }
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     const double v[3] = {a.vx[i], a.vy[i], a.vz[i]};
     double pa[3], vis[3];
@@ -233,9 +273,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     a.T[i] = T;
 }
 
-int sphx_integrate(sphx_ctx* ctx, int64_t n) {
+int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixed_dt) {
     StateArrays& s = ctx->st;
     IntegArgs a;
+    a.ct_bits = fold_dt ? ctx->scal.as<u64>() + SC_CT_BITS : nullptr;
+    a.dt_out = ctx->scal.as<double>() + SC_DT;
+    a.first = first; a.fixed_dt = fixed_dt; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
     a.n = (int)n;
     a.x = s.x.as<double>(); a.y = s.y.as<double>(); a.z = s.z.as<double>();
     a.vx = s.vx.as<double>(); a.vy = s.vy.as<double>(); a.vz = s.vz.as<double>();
@@ -359,6 +402,7 @@ extern "C" int sphx_leapfrog(sphx_ctx* ctx, int64_t n, double* points, double* v
     double* dtd = ctx->scal.as<double>() + 15;          // a slot nothing else uses
     HIPCHK(hipMemcpyAsync(dtd, &dt, 8, hipMemcpyHostToDevice, ctx->stream));
     IntegArgs a;
+    a.ct_bits = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = 0.0; a.max_age = 0.0;
     a.n = (int)n;
     a.x = x; a.y = y; a.z = z; a.vx = vx; a.vy = vy; a.vz = vz; a.ax = ax; a.ay = ay; a.az = az;
     a.E = E; a.T = Tt; a.m = m; a.mu = muu; a.gam = gm; a.ptype = pt;

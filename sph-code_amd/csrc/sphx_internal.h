@@ -98,6 +98,7 @@ struct sphx_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t side_stream = nullptr;  // independent work beside the main chain (record build while the lists are deduplicated)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_perm_fork = nullptr, ev_perm = nullptr;   // the state's permutation split over the two streams (sphx_permute_state)
     double dev_hmean = 0.0;             // device API: mean h of the previous search (cell size)
     bool knn_hint_by_id = false;        // device API: search-radius hints are in caller order
     char err[512] = {0};
@@ -153,6 +154,7 @@ struct sphx_ctx {
     double *clamp_vx = nullptr, *clamp_vy = nullptr, *clamp_vz = nullptr;   // set by the step: the grid build applies drv:233-238
     bool bbox_ticket_zeroed = false;
     bool defer_cell_sort = false, cells_unsorted = false;   // the per-cell member sort rides in the blob-order pass
+    bool split_perm = true;         // SPHX_SPLIT_PERM=0: the whole state permuted in one launch before the search
     bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
     bool knn_hinted = false;        // set by the callers of sphx_knn whose rsearch holds real previous radii
     DevBuf fail_list;               // queries the grouped kernel hands to the general one (+ their count)
@@ -166,6 +168,9 @@ struct sphx_ctx {
     bool olev_ev_valid = false;
     u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
     int64_t farq_last = 0;          // far queries met by the previous hinted search
+    bool knn_lag_external = false;  // the caller copies SC_NFAILQ .. SC_BADHINT out behind the search and hands them back
+    bool knn_lag_valid = false;
+    u64 knn_lag[4] = {0, 0, 0, 0};
     // hint distrust (an experiment kept as an option, off by default): skip the grouped kernel and seed every radius
     // from the local cell counts.  Auto mode enters when the previous hinted search left more than a quarter of its
     // queries to the general kernel (a diverging run: particles move by several h per step) and leaves once fewer than
@@ -343,10 +348,10 @@ int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmaj
 
 // integrate / layout helpers (sphx_integrate.hip)
 int sphx_clamp(sphx_ctx* ctx, int64_t n, StateArrays& s);
-int sphx_permute_state(sphx_ctx* ctx, int64_t n);
+int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split = false);
 int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h);
 int sphx_compute_dt(sphx_ctx* ctx, int first, double fixed_dt);
-int sphx_integrate(sphx_ctx* ctx, int64_t n);
+int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt = 0, int first = 0, double fixed_dt = 0.0);
 int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const double* ptype, const double* mgm,
                    const double* mcs);
 int sphx_aos_to_soa3(sphx_ctx* ctx, int64_t n, const double* aos, double* x, double* y, double* z);

@@ -729,10 +729,12 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         const size_t tile_bytes = (size_t)k * (KNN_PPB + 1) * sizeof(int);
         // What the previous hinted search reported (copied out behind it, on the host long since: no wait): queries it
         // left to the general kernel, far queries (outside the grid box, wide spheres), radii that contradicted their hints
+        // (the fused loop copies these slots out together with its mean-h read-back and hands them over: knn_lag_*)
         const bool lagged = ctx->olev_mode == 2 || ctx->distrust_mode == 2;
-        if (lagged && ctx->olev_ev_valid) {
-            HIPCHK(hipEventSynchronize(ctx->olev_ev));
-            const u64* v = (const u64*)((const char*)ctx->pinned + 3072);        // slots SC_NFAILQ .. SC_BADHINT
+        const bool ext = ctx->knn_lag_external;
+        if (lagged && (ext ? ctx->knn_lag_valid : ctx->olev_ev_valid)) {
+            if (!ext) HIPCHK(hipEventSynchronize(ctx->olev_ev));
+            const u64* v = ext ? ctx->knn_lag : (const u64*)((const char*)ctx->pinned + 3072);   // slots SC_NFAILQ .. SC_BADHINT
             const int64_t fb = (int64_t)(u32)v[0];
             ctx->farq_last = (int64_t)(v[2] >= ctx->farq_seen ? v[2] - ctx->farq_seen : v[2]);
             ctx->farq_seen = v[2];
@@ -743,6 +745,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
                 else ctx->distrust = bad * 20 > n;
             }
             ctx->olev_ev_valid = false;
+            ctx->knn_lag_valid = false;
         }
         if (ctx->distrust_mode != 2) ctx->distrust = ctx->distrust_mode == 1;
         // Outlier levels: built when that search met many far queries - a diverging run's escapers, an expanding cloud's rim
@@ -801,7 +804,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(ctx->scal.as<u64>() + SC_NFAILQ, fcount, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         }
-        if (lagged) {
+        if (lagged && !ext) {
             if (!ctx->olev_ev) HIPCHK(hipEventCreateWithFlags(&ctx->olev_ev, hipEventDisableTiming));
             HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 3072, ctx->scal.as<u64>() + SC_NFAILQ, 4 * sizeof(u64), hipMemcpyDeviceToHost,
                                   ctx->stream));
