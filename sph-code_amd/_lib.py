@@ -7,7 +7,7 @@ import weakref
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsphx.so")
+LIB_PATH = os.environ.get("SPHX_LIB") or os.path.join(HERE, "libsphx.so")     # (SPHX_LIB: another build of the same library)
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)

@@ -19,8 +19,8 @@
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
 #ifndef KNN_LIST_BLOCKS
-#define KNN_LIST_BLOCKS 2048
-#endif
+#define KNN_LIST_BLOCKS 512     // list mode: workgroups walking the list (measured at 1e6 particles, 1.5 % of them listed:
+#endif                          // 256: 0.579 ms search, 384: 0.561, 512: 0.555, 1024: 0.575, 2048: 0.617, 4096: 0.70)
 #ifndef KNN_LIST_PPB
 #define KNN_LIST_PPB 16     // list mode: queries per workgroup and pass
 #endif
@@ -154,6 +154,9 @@ __device__ __forceinline__ void block27_count(const GridParams& g, const int* ce
 // OUTL = 1 (list mode only): a query OUTSIDE the grid box whose search sphere is wider than OLEV_MIN_RC cells does not walk
 // the grid's boundary faces (every escaper hashed there: whole faces of one-particle rows) but the outlier levels its
 // sphere can reach (OutLevels) and then the grid with the outliers filtered out - the same candidates, each exactly once.
+#ifndef SPHX_KNN_PROF_LONG
+#define SPHX_KNN_PROF_LONG 10000000ull     // -DSPHX_KNN_PROF builds: a query taking more cycles than this is described
+#endif
 #ifndef KNN_LIST_WAVES
 #define KNN_LIST_WAVES 4     // list / outlier-level variants: fewer, fatter waves (the prefetched batch needs registers)
 #endif
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             const int pc = prof_cat >= 2 ? 1 : 0;
             p_sum[pc] += dtc; p_n[pc] += 1; p_tries[pc] += (u64)(tries + 1);
             if (dtc > p_max[pc]) p_max[pc] = dtc;
-            if (dtc > 10000000ull && lane == 0 && a.counters) {        // a monster: who is it?
+            if (dtc > SPHX_KNN_PROF_LONG && lane == 0 && a.counters) {        // a monster: who is it?
                 double* dbg = (double*)(a.counters + SC_KNNPROF + 16);
                 dbg[0] = xi; dbg[1] = yi; dbg[2] = zi; dbg[3] = R_given; dbg[4] = hval; dbg[5] = (double)tries;
                 dbg[6] = (double)(ncand - prof_c0); dbg[7] = (double)dtc;
