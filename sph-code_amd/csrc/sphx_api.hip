@@ -86,6 +86,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
     if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
     if (const char* e = getenv("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
@@ -791,8 +792,22 @@ int sphx_agb_table_set(sphx_ctx* ctx, int S, int nspl, const int32_t* ntx, const
     }
     for (int s = 0; s < S; ++s) t.mu[s] = mu_specie[s];
     t.divisor = divisor; t.solar = solar_mass;
-    SPHX_TRY(sphx_ensure(ctx, ctx->agb_knots, (ntx_tot + nty_tot + nc_tot) * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->agb_knots, (ntx_tot + nty_tot + nc_tot + 6 * (size_t)nspl) * sizeof(double)));
     double* kd = ctx->agb_knots.as<double>();
+    {   // the per-spline integers once more, in device memory (AgbTable::meta_off)
+        double meta[6 * AGB_MAX_SPL];
+        t.covered = 0u;
+        for (int o = 0; o < nspl; ++o) {
+            bool later = false;
+            for (int o2 = o + 1; o2 < nspl; ++o2) later = later || mapto[o2] == mapto[o];
+            meta[6 * o + 0] = t.tx_off[o]; meta[6 * o + 1] = t.ty_off[o]; meta[6 * o + 2] = t.c_off[o];
+            meta[6 * o + 3] = t.ntx[o]; meta[6 * o + 4] = t.nty[o]; meta[6 * o + 5] = later ? -1.0 : (double)mapto[o];
+            t.covered |= 1u << mapto[o];
+        }
+        t.meta_off = (int)(ntx_tot + nty_tot + nc_tot);
+        HIPCHK(hipMemcpyAsync(kd + t.meta_off, meta, 6 * (size_t)nspl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));       // (meta is a stack array)
+    }
     HIPCHK(hipMemcpyAsync(kd, tx, ntx_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(kd + ntx_tot, ty, nty_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(kd + ntx_tot + nty_tot, coeffs, nc_tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));

@@ -496,6 +496,176 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, 
     }
 }
 
+// ---- species pass (nsc:624-627) out of LDS, + metallicity and AGB yields ---------------------------
+// F[s,i] = sum_k Nw_j W_ij f_un[j,s] needs, per neighbour, the 64-B record (for W) AND the 128-B composition row: 184 KB
+// for a blob's 960 slots, more than a CU has.  So the blob is walked three times over the same slot lists: (1) the
+// records are staged and every lane turns its list positions into weights Nw_j W_ij kept in REGISTERS (K/4 doubles);
+// (2), (3) the image is refilled with the lower / upper 64 bytes of the distinct neighbours' composition rows and the
+// lane accumulates weight x row.  Each distinct row is fetched once per blob (~5 per particle) instead of once per
+// reference (40 per particle: the gather form, sphx_sums.hip, bound by exactly that: 1.77 ms at 1e6 particles).
+// Sums: the lane's positions k = q mod 4 in ascending k, then (p0 + p1) + (p2 + p3) as in the other LDS passes.
+// SPEC_MAXM: list positions per lane the registers are sized for (K <= 40: 10; else 16)
+template <int SPEC_MAXM>
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int n, int npad, int k, int nblk, int S,
+                                                              const int* __restrict__ nbr,
+                                                              const u16* __restrict__ slot16,
+                                                              const int* __restrict__ uniq,
+                                                              const int* __restrict__ qorder,
+                                                              const RecA* __restrict__ rec,
+                                                              const double* __restrict__ fun,       // rows of 16 doubles
+                                                              const double* __restrict__ m, AgbTable agb, int agb_on,
+                                                              double* F, double* Zout, double* agb_out) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
+    u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
+    const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);
+    const int nm = KPAD(k) / LPP;
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const bool live = p < n;
+        const int i = live ? qorder[p] : 0;
+        const int* uq = uniq + (size_t)b * BLOB_S;
+        stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uq, slot16, npad, k, b);
+        __syncthreads();
+        // ---- (1) weights of this lane's list positions
+        double w[SPEC_MAXM];
+        {
+            double xr, yr, zr;
+            {
+                const int j0 = live ? nbr[p] : 0;                   // deltas are relative to the first neighbour (nsc:580-581)
+                const unsigned sl0 = tile[t];
+                if (sl0 < SLOT_OVER) { const Q4 r = lload4(img, (int)sl0, 0); xr = r.a; yr = r.b; zr = r.c; }
+                else { const int jj = j0 < 0 ? i : j0; xr = rec[jj].x; yr = rec[jj].y; zr = rec[jj].z; }
+            }
+#pragma unroll
+            for (int mm = 0; mm < SPEC_MAXM; ++mm) {
+                w[mm] = 0.0;
+                if (mm < nm) {
+                    const unsigned sl = tile[(LPP * mm + half) * BLOB_P + t];
+                    if (sl != SLOT_NONE && live) {
+                        Q4 q0, q1;
+                        if (sl < SLOT_OVER) { q0 = lload4(img, (int)sl, 0); q1 = lload4(img, (int)sl, 1); }
+                        else {
+                            const double* q = reinterpret_cast<const double*>(&rec[nbr[(size_t)(LPP * mm + half) * npad + p]]);
+                            q0 = gload4(q); q1 = gload4(q + 4);
+                        }
+                        const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
+                        const double r = sqrt_mid(dx * dx + dy * dy + dz * dz);
+                        const double qj = q0.d - r * r;
+                        double W = q1.a * (qj * qj * qj);
+                        W = (W < 0.0) ? 0.0 : W;
+                        w[mm] = q1.d * W;
+                    }
+                }
+            }
+        }
+        double tot[16];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            __syncthreads();                                   // everybody is done with the previous image
+            // ---- (2), (3): this half of the distinct neighbours' composition rows into the image
+            {
+                int ju[NSTAGE];
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const int s = threadIdx.x + r * PASS_T;
+                    ju[r] = (s < BLOB_S) ? uq[s] : -1;
+                }
+                double2 c[NSTAGE][4];
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const double2* g = reinterpret_cast<const double2*>(fun + (size_t)(ju[r] < 0 ? 0 : ju[r]) * 16) + 4 * hh;
+                    c[r][0] = g[0]; c[r][1] = g[1]; c[r][2] = g[2]; c[r][3] = g[3];
+                }
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const int s = threadIdx.x + r * PASS_T;
+                    if (ju[r] >= 0) {
+                        img[0 * BLOB_S + s] = c[r][0]; img[1 * BLOB_S + s] = c[r][1];
+                        img[2 * BLOB_S + s] = c[r][2]; img[3 * BLOB_S + s] = c[r][3];
+                    }
+                }
+            }
+            __syncthreads();
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int mm = 0; mm < SPEC_MAXM; ++mm) {
+                if (mm < nm) {
+                    const unsigned sl = tile[(LPP * mm + half) * BLOB_P + t];
+                    if (sl != SLOT_NONE && live) {
+                        Q4 f0, f1;
+                        if (sl < SLOT_OVER) { f0 = lload4(img, (int)sl, 0); f1 = lload4(img, (int)sl, 1); }
+                        else {
+                            const double* q = fun + (size_t)nbr[(size_t)(LPP * mm + half) * npad + p] * 16 + 8 * hh;
+                            f0 = gload4(q); f1 = gload4(q + 4);
+                        }
+                        const double wm = w[mm];
+                        acc[0] += wm * f0.a; acc[1] += wm * f0.b; acc[2] += wm * f0.c; acc[3] += wm * f0.d;
+                        acc[4] += wm * f1.a; acc[5] += wm * f1.b; acc[6] += wm * f1.c; acc[7] += wm * f1.d;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tot[8 * hh + q] = group_total(acc[q]);
+        }
+        if (live && !half) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < S) F[(size_t)q * n + i] = tot[q];
+        }
+        if (live && agb_on) {
+            // every lane of the group holds the totals: the metallicity in all four, the splines dealt over them
+            double heavy = 0.0, all = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < S) {
+                    const double ww = tot[q] * agb.mu[q];
+                    all += ww;
+                    if (q >= 6) heavy += ww;
+                }
+            }
+            const double Z = heavy / all;                      // drv:663
+            if (!half) Zout[i] = Z;
+            const double Mi = m[i];
+            double* row = agb_out + (size_t)i * S;
+            for (int q = half; q < S; q += LPP)
+                if (!((agb.covered >> q) & 1u)) row[q] = 0.0;  // species no spline writes
+            for (int o = half; o < agb.nspl; o += LPP) {
+                double val;
+                const int target = agb_one_spline(agb, o, Mi, Z, val);
+                if (target >= 0) row[target] = val;
+            }
+        }
+        __syncthreads();                                       // the image is rewritten by the next blob
+    }
+}
+
+int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_sorted, const double* m_sorted, double* F,
+                      double* Z, double* agb, int agb_on) {
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_species_kernel<10>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_species_kernel<16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+        attr = true;
+    }
+    if (KPAD(k) / LPP <= 10)
+        hipLaunchKernelGGL(blob_species_kernel<10>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n,
+                           (int)npad, k, nblk, S, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,
+                           ctx->rec1.as<RecA>(), fun_sorted, m_sorted, ctx->agb, agb_on, F, Z, agb);
+    else
+        hipLaunchKernelGGL(blob_species_kernel<16>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n,
+                           (int)npad, k, nblk, S, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,
+                           ctx->rec1.as<RecA>(), fun_sorted, m_sorted, ctx->agb, agb_on, F, Z, agb);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
 int sphx_blob_grid(sphx_ctx* ctx, int nblk) {

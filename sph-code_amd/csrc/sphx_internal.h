@@ -154,6 +154,7 @@ struct sphx_ctx {
     double *clamp_vx = nullptr, *clamp_vy = nullptr, *clamp_vz = nullptr;   // set by the step: the grid build applies drv:233-238
     bool bbox_ticket_zeroed = false;
     bool defer_cell_sort = false, cells_unsorted = false;   // the per-cell member sort rides in the blob-order pass
+    bool species_lds = true;        // SPHX_SPECIES_LDS=0: the species pass by gathers (sphx_sums.hip) also when blob lists exist
     bool split_perm = true;         // SPHX_SPLIT_PERM=0: the whole state permuted in one launch before the search
     bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
     bool knn_hinted = false;        // set by the callers of sphx_knn whose rsearch holds real previous radii
@@ -313,6 +314,8 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits);
 int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
+int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_sorted, const double* m_sorted, double* F,
+                      double* Z, double* agb, int agb_on);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
 int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const double* ys, const double* zs);   // (sorted order)

@@ -110,7 +110,7 @@ def test_gpu_yields_bad_arguments(g):
 
 
 @pytest.mark.gpu
-def test_step_species_pass_with_fused_metallicity_and_agb_yields(g):
+def test_step_species_pass_with_fused_metallicity_and_agb_yields(g, monkeypatch):
     """BASELINE configs[4] in small: two-phase gas + dust (drv:120-152), every step also forms F[s,i] (nsc:624-627) on
     its own neighbour list and, in the same pass, the per-particle metallicity (the expression of drv:663 on the
     smoothed composition) and the AGB dust yields (config_helper.py:183-189) at (Z_i, m_i).  Oracle: a composition of
@@ -146,8 +146,17 @@ def test_step_species_pass_with_fused_metallicity_and_agb_yields(g):
                                          np.ones((fin.sum(), 15)), mapto=g["mapto"], divisor=float(g["divisor"]))
     np.testing.assert_allclose(got["agb_dust"][fin], dust, rtol=1e-12, atol=0)
     assert (got["agb_dust"][fin][:, [7, 8, 10, 11, 12, 13]] > 0).any()
-    # the array API's species sums agree with the step's (same list): bit for bit
+    # The array API's species sums (gathers, list positions added in ascending k) against the step's on the same list.
+    # The step's LDS form (sphx_blob.hip blob_species_kernel: each distinct neighbour's composition row staged once per
+    # blob) adds four partial sums over k mod 4 as (p0 + p1) + (p2 + p3): equal to rounding; with SPHX_SPECIES_LDS=0 the
+    # step runs the gather form too and the two agree bit for bit.
     import sph_code_amd.compat as nsc
     idx, _, _, _, hh = nsc.neighbors(p, np.inf, K)
     F2 = nsc.hydro_update(idx, p, s["mass"], hh, s["f_un"], s["particle_type"], s["T"], s["mu_array"], s["gamma_array"], v)[5]
-    assert np.array_equal(F2, got["f_un_neighbor"])
+    np.testing.assert_allclose(got["f_un_neighbor"], F2, rtol=1e-14, atol=0)
+    monkeypatch.setenv("SPHX_SPECIES_LDS", "0")
+    sim_g = Simulation(s, n_neigh=K, with_species=True, agb=table)
+    sim_g.step(1)
+    got_g = sim_g.download_species()
+    assert np.array_equal(F2, got_g["f_un_neighbor"])
+    np.testing.assert_allclose(got["metallicity"][fin], got_g["metallicity"][fin], rtol=1e-13)
