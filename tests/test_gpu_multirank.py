@@ -68,6 +68,34 @@ def test_one_rank_device_api_matches_fused_step_in_loop_form_mode():
         np.testing.assert_allclose(b[key][order], a[key], rtol=1e-13, atol=0, err_msg=key)
 
 
+def test_one_rank_device_api_search_with_outlier_levels_is_exact(monkeypatch):
+    """The device-pointer search (sphx_dev_search: hints by caller index, radii written by id - knn_kernel<0,2,...>) on a
+    core with a halo of escapers spread over five decades: with the outlier levels built (SPHX_OUTLIER_LEVELS=1) every
+    radius still equals the exact K-th-neighbour distance (cKDTree, eps = 0), hinted and unhinted."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd import multigpu as mg
+    monkeypatch.setenv("SPHX_OUTLIER_LEVELS", "1")
+    n_core, n_halo = 30000, 5000
+    rs = np.random.RandomState(5)
+    core = (rs.rand(n_core, 3) - 0.5) * 2e17
+    u = rs.normal(size=(n_halo, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    pts = np.ascontiguousarray(np.concatenate([core, u * (10.0 ** rs.uniform(17.2, 21.5, n_halo))[:, None]]))
+    _, _, _, _, h_ref = orc.neighbors(pts, np.inf, K, eps=0.0)
+    be = mg.LibBackend(0, k=K)
+    pos = torch.as_tensor(pts, device="cuda:0")
+    n = pts.shape[0]
+    h0 = be.search(pos, n, None, 0.0)                                   # no hints
+    assert np.array_equal(h0.cpu().numpy(), h_ref)
+    for scale in (1.0, 0.3, 4.0):                                       # good, too small and far too large hints
+        h1 = be.search(pos, n, (h0 * scale).contiguous(), float(h0.mean()))
+        assert np.array_equal(h1.cpu().numpy(), h_ref), scale
+    st = be.ctx.stats()
+    assert st["outlier_levels"] > 0 and st["short_rows"] == 0
+    torch.cuda.synchronize()
+
+
 def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update", c5=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
