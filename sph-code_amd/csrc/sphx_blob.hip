@@ -69,6 +69,21 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
                 const int kk = 2 * (m0 + DD_BATCH + u) + half;
                 jn[u] = (kk < k && live) ? nbr[(size_t)kk * npad + p] : -1;
             }
+            // first probe of the whole batch side by side (the table is sparse: 1.2 probes on average, so nearly every
+            // reference is settled here with its LDS round trips overlapped instead of chained), then the stragglers
+            unsigned hb[DD_BATCH];
+            int eb[DD_BATCH];
+#pragma unroll
+            for (int u = 0; u < DD_BATCH; ++u) {
+                hb[u] = dd_hash(jb[u] < 0 ? 0 : jb[u]);
+                eb[u] = key[hb[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < DD_BATCH; ++u)
+                if (jb[u] >= 0 && eb[u] == -1) {
+                    const int old = atomicCAS(&key[hb[u]], -1, jb[u]);
+                    eb[u] = (old == -1) ? jb[u] : old;
+                }
 #pragma unroll
             for (int u = 0; u < DD_BATCH; ++u) {
                 const int kk = 2 * (m0 + u) + half;
@@ -76,16 +91,20 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
                 const int j = jb[u];
                 unsigned s = SLOT_NONE;
                 if (j >= 0) {
-                    unsigned h = dd_hash(j);
+                    unsigned h = hb[u];
                     s = SLOT_OVER;
-                    for (int probe = 0; probe < DD_PROBES; ++probe) {
-                        int e = key[h];
-                        if (e == -1) {
-                            e = atomicCAS(&key[h], -1, j);
-                            if (e == -1) e = j;
+                    if (eb[u] == j) {
+                        s = h;
+                    } else {
+                        for (int probe = 1; probe < DD_PROBES; ++probe) {
+                            h = (h + 1) & (DD_TAB - 1);
+                            int e = key[h];
+                            if (e == -1) {
+                                e = atomicCAS(&key[h], -1, j);
+                                if (e == -1) e = j;
+                            }
+                            if (e == j) { s = h; break; }
                         }
-                        if (e == j) { s = h; break; }
-                        h = (h + 1) & (DD_TAB - 1);
                     }
                 }
                 dd_tile[kk * BLOB_P + t] = (u16)s;
