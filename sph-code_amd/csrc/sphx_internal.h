@@ -169,6 +169,7 @@ struct sphx_ctx {
     bool olev_ev_valid = false;
     u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
     int64_t farq_last = 0;          // far queries met by the previous hinted search
+    int64_t list_len_last = 0;      // queries the previous hinted search left to the general kernel (sizes the list-mode grid)
     bool knn_lag_external = false;  // the caller copies SC_NFAILQ .. SC_BADHINT out behind the search and hands them back
     bool knn_lag_valid = false;
     u64 knn_lag[4] = {0, 0, 0, 0};

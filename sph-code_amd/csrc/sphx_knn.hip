@@ -19,8 +19,11 @@
 #define KNN_BLOCK 256
 #define KNN_PPB 64          // particles per workgroup (16 per wave)
 #ifndef KNN_LIST_BLOCKS
-#define KNN_LIST_BLOCKS 512     // list mode: workgroups walking the list (measured at 1e6 particles, 1.5 % of them listed:
-#endif                          // 256: 0.579 ms search, 384: 0.561, 512: 0.555, 1024: 0.575, 2048: 0.617, 4096: 0.70)
+#define KNN_LIST_BLOCKS 512     // list mode: workgroups walking the list, at least (measured at 1e6 particles, 1.5 % of them
+#endif                          // listed: 256: 0.579 ms search, 384: 0.561, 512: 0.555, 1024: 0.575, 2048: 0.617, 4096: 0.70;
+#ifndef KNN_LIST_BLOCKS_MAX     // 7 % listed - the uniform cube's faces: 512: 1.12, 768: 0.99, 1024: 0.93, 2048: 0.92) - the
+#define KNN_LIST_BLOCKS_MAX 2048 // launcher sizes the grid from the previous search's list: one workgroup per 32 entries
+#endif
 #ifndef KNN_LIST_PPB
 #define KNN_LIST_PPB 16     // list mode: queries per workgroup and pass
 #endif
@@ -739,6 +742,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             if (!ext) HIPCHK(hipEventSynchronize(ctx->olev_ev));
             const u64* v = ext ? ctx->knn_lag : (const u64*)((const char*)ctx->pinned + 3072);   // slots SC_NFAILQ .. SC_BADHINT
             const int64_t fb = (int64_t)(u32)v[0];
+            ctx->list_len_last = fb;
             ctx->farq_last = (int64_t)(v[2] >= ctx->farq_seen ? v[2] - ctx->farq_seen : v[2]);
             ctx->farq_seen = v[2];
             const int64_t bad = (int64_t)(v[3] >= ctx->badhint_seen ? v[3] - ctx->badhint_seen : v[3]);
@@ -796,7 +800,9 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
             SPHX_TRY(sphx_knn_group(ctx, ga));
             a.qlist = flist; a.qcount = fcount;
-            int lblocks = blocks < KNN_LIST_BLOCKS ? blocks : KNN_LIST_BLOCKS;
+            int lblocks = (int)((ctx->list_len_last / 32 + 255) / 256) * 256;
+            lblocks = lblocks < KNN_LIST_BLOCKS ? KNN_LIST_BLOCKS : (lblocks > KNN_LIST_BLOCKS_MAX ? KNN_LIST_BLOCKS_MAX : lblocks);
+            if (lblocks > blocks) lblocks = blocks;
             if (a.ol.L > 0) {
                 if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
                 else hipLaunchKernelGGL((knn_kernel<0, 2, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
