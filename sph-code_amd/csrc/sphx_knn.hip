@@ -204,11 +204,16 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
     {
         const int ip = base + wave * (PPB / 4) + (lane & 15);
         if (lane < PPB / 4 && ip < total) {
-            const int slot = LIST ? a.qlist[ip] : ip;
+            // (a list entry: processing slot in the low 29 bits; in the top three, how much wider than the hint to start -
+            //  the grouped kernel counted fewer than K inside it: 1 .. 7 = x1.6 .. x3, sphx_knn_group.hip)
+            const unsigned raw = LIST ? (unsigned)a.qlist[ip] : (unsigned)ip;
+            const int slot = (int)(raw & 0x1FFFFFFFu);
+            const unsigned gc = LIST ? raw >> 29 : 0u;
             qs = a.qorder ? a.qorder[slot] : slot;
             qx = a.x[qs]; qy = a.y[qs]; qz = a.z[qs];
             qid = a.id[qs];
             qr = a.rsearch ? a.rsearch[a.hint_by_id ? qid : qs] * a.rscale : 0.0;
+            if (gc) qr *= 1.6 + (double)(gc - 1u) * (1.4 / 6.0);
         }
     }
 
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
         __syncthreads();
         if (LIST) {
             const int i = base + lane;
-            const int slot = (lane < PPB && i < total) ? a.qlist[i] : -1;
+            const int slot = (lane < PPB && i < total) ? (int)((unsigned)a.qlist[i] & 0x1FFFFFFFu) : -1;
             for (int kk = wave; kk < K; kk += KNN_BLOCK / 64)
                 if (slot >= 0) a.nbr[(long long)kk * a.npad + slot] = tile(kk, lane);
             __syncthreads();                           // the tile is reused by the next list chunk

@@ -395,7 +395,16 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     const int pq = xcd_block(blockIdx.x, gridDim.x) * 64 + src;             // the query's processing slot = list column
     const int cnt = cntq[src];
     bool okq = q_ok0, failq = q_fail0;
-    if (okq && (cnt > 64 || cnt < K)) { okq = false; failq = true; q_why = cnt > 64 ? 4 : 5; }
+    // (a query with fewer than K inside its radius tells the general kernel how much wider to start: the count sizes the
+    //  step as in its own ladder, x1.6 .. x3 in eight steps, carried in the list entry's top three bits)
+    unsigned grow_code = 0;
+    if (okq && (cnt > 64 || cnt < K)) {
+        okq = false; failq = true; q_why = cnt > 64 ? 4 : 5;
+        if (cnt < K) {
+            const float gr = fminf(fmaxf(cbrtf(1.5f * (float)K / (float)(cnt > 0 ? cnt : 1)), 1.6f), 3.0f);
+            grow_code = 1u + (unsigned)((gr - 1.6f) * (6.0f / 1.4f) + 0.5f);
+        }
+    }
     const int maxcnt = (int)wmax((double)(okq ? cnt : 0));
 
     // ---- phase B: the lane's 16 list entries -> keys ----
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         int base = 0;
         if (lane == 0) base = atomicAdd(a.fail_count, __popcll(failmask));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (failq && rep) a.fail_list[base + lanes_below(failmask)] = pq;
+        if (failq && rep) a.fail_list[base + lanes_below(failmask)] = (int)((unsigned)pq | (grow_code << 29));
         if (a.counters) {
             for (int wq = 1; wq <= 6; ++wq) {
                 const u64 mk = __builtin_amdgcn_ballot_w64(failq && rep && q_why == wq);
