@@ -233,7 +233,8 @@ int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* pos, const 
 /* Enable the dust->gas drag of nsc.net_impulse (nsc:719-742) inside the step loop:
  * visc_accel = drag*rho_dust/rho*[gas] + reaction + viscous accel (drv:455,462-463,473).
  * mean_grain_mass / mean_cross (n,) as in sphx_net_impulse; NULL disables.  Call directly after
- * sphx_state_upload.  The reaction is a scatter-add (float atomics): not bitwise reproducible. */
+ * sphx_state_upload.  The reaction (nsc:741) is an ordered scatter: contributions added by source particle (caller
+ * index), then list position - np.add.at's order, the same bits on every run (n*K*32 B of device memory). */
 int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass, const double* mean_cross);
 /* Species pass inside the step: when sphx_state_upload was given f_un, every sphx_step (hydro_update mode) also forms
  * F[s,i] = sum_k m_j/(mu_j amu) [gas_j] f_un[j,s] W (nsc:624-627) on its own neighbour list.  With an AGB table set

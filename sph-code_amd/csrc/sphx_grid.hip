@@ -248,6 +248,8 @@ static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
     return SPHX_OK;
 }
 
+int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n) { return excl_scan_plus_total(ctx, in, out, n); }
+
 // three-phase exclusive scan of int32: 2048 items per block
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256

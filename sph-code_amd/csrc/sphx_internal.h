@@ -113,6 +113,8 @@ struct sphx_ctx {
     DevBuf rec1, recv;            // RecA[n], RecB[n]
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
+    DevBuf ds_cnt, ds_start, ds_keys, ds_vals;   // ordered scatter of the reaction (DragScatter)
+    const void* ds_cnt_zeroed = nullptr;
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
     bool dev_ev_pending = false;  // sphx_dev_search recorded ev[1]/ev[2] around its kNN launch: not yet read
     int loop_forms = 0;           // step mode: the loop forms of the reference's time loop (sphx_state_set_loop_forms)
@@ -319,6 +321,14 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
                       double* Z, double* agb, int agb_on);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
+int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n);   // out[0..n] = exclusive prefix sums, out[n] = total (in[n] must be 0)
+// The drag reaction (nsc:741: every particle adds -f to each of its dust neighbours) as an ORDERED scatter: the
+// contributions to a particle are first laid side by side (slices from a count + scan), then added in the order the
+// reference's np.add.at adds them - by source particle (caller index), then list position - so the sum is the same bits on
+// every run, and the reference's.  sphx_drag_scatter_plan: count + scan; the drag kernels fill; sphx_drag_scatter_reduce adds.
+struct DragScatter { int* cnt; const int* start; u64* keys; double* vals; };
+int sphx_drag_scatter_plan(sphx_ctx* ctx, int64_t n, int k, const int* nbr, const double* ptype, const int* qorder, DragScatter* out);
+int sphx_drag_scatter_reduce(sphx_ctx* ctx, int64_t n, const DragScatter& d, double* react);
 int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const double* ys, const double* zs);   // (sorted order)
 // knn
 struct KnnOut {

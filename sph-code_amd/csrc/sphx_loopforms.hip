@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void loop_ct_kernel(LoopArgs a) {
     }
 }
 
-// nsc:719-742 (reaction is a scatter-add: float atomics, order not reproducible bit for bit)
-__global__ __launch_bounds__(256) void loop_impulse_kernel(LoopArgs a) {
+// nsc:719-742; the reaction as an ordered scatter (DragScatter, sphx_internal.h): np.add.at's order, the same bits every run
+__global__ __launch_bounds__(256) void loop_impulse_kernel(LoopArgs a, DragScatter sc) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const double xi = a.pos[3 * (size_t)i], yi = a.pos[3 * (size_t)i + 1], zi = a.pos[3 * (size_t)i + 2];
@@ -177,16 +177,18 @@ __global__ __launch_bounds__(256) void loop_impulse_kernel(LoopArgs a) {
         const double dx = a.pos[3 * (size_t)j] - xi, dy = a.pos[3 * (size_t)j + 1] - yi,
                      dz = a.pos[3 * (size_t)j + 2] - zi;
         const double wf = weigh2_dust(dx * dx + dy * dy + dz * dz, a.m[j], a.h[j]);
-        if (!(wf > 0.0)) continue;
-        const double dvx = a.vel[3 * (size_t)j] - vxi, dvy = a.vel[3 * (size_t)j + 1] - vyi,
-                     dvz = a.vel[3 * (size_t)j + 2] - vzi;
-        const double coef = wf / a.mgm[j] * a.mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
-        const double fx = coef * dvx, fy = coef * dvy, fz = coef * dvz;
-        ox += fx; oy += fy; oz += fz;
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        if (wf > 0.0) {
+            const double dvx = a.vel[3 * (size_t)j] - vxi, dvy = a.vel[3 * (size_t)j + 1] - vyi,
+                         dvz = a.vel[3 * (size_t)j + 2] - vzi;
+            const double coef = wf / a.mgm[j] * a.mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
+            fx = coef * dvx; fy = coef * dvy; fz = coef * dvz;
+            ox += fx; oy += fy; oz += fz;
+        }
         if (j != i) {
-            atomicAdd(&a.out3b[3 * (size_t)j], -fx);
-            atomicAdd(&a.out3b[3 * (size_t)j + 1], -fy);
-            atomicAdd(&a.out3b[3 * (size_t)j + 2], -fz);
+            const int slot = sc.start[j] + atomicSub(&sc.cnt[j], 1) - 1;
+            sc.keys[slot] = ((u64)(unsigned)i << 12) | (u64)kk;
+            sc.vals[3 * (size_t)slot] = -fx; sc.vals[3 * (size_t)slot + 1] = -fy; sc.vals[3 * (size_t)slot + 2] = -fz;
         }
     }
     a.out3[3 * (size_t)i] = ox; a.out3[3 * (size_t)i + 1] = oy; a.out3[3 * (size_t)i + 2] = oz;
@@ -363,8 +365,11 @@ extern "C" int sphx_net_impulse(sphx_ctx* ctx, int64_t n, int k, const double* p
     SPHX_TRY(sphx_ensure(ctx, ctx->out_b, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->out_c, (size_t)n * 3 * sizeof(double)));
     a.out3 = ctx->out_b.as<double>(); a.out3b = ctx->out_c.as<double>();
-    HIPCHK(hipMemsetAsync(a.out3b, 0, (size_t)n * 3 * sizeof(double), ctx->stream));
-    LAUNCH1(loop_impulse_kernel);
+    DragScatter sc;
+    SPHX_TRY(sphx_drag_scatter_plan(ctx, n, k, a.nbr, a.pt, nullptr, &sc));
+    hipLaunchKernelGGL(loop_impulse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, sc);
+    HIPCHK(hipGetLastError());
+    SPHX_TRY(sphx_drag_scatter_reduce(ctx, n, sc, a.out3b));
     SPHX_TRY(down(ctx, accel_onto, a.out3, (size_t)n * 3 * sizeof(double)));
     return down(ctx, accel_reaction, a.out3b, (size_t)n * 3 * sizeof(double));
 }

@@ -11,6 +11,7 @@
 // variants agree bit for bit.  In registers, no atomics: results are bitwise reproducible.
 // Deltas are taken relative to nbr[0][i] (the reference subtracts neighbour 0, nsc:580-581).
 #include "sphx_internal.h"
+#include "sphx_wave.h"
 // NumPy never fuses a multiply into an add: keep every operation separately rounded so that
 // cancellations such as h_j^2 - r^2 at the kernel edge reproduce the reference bit for bit.
 #pragma clang fp contract(off)
@@ -399,18 +400,141 @@ int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
     return SPHX_OK;
 }
 
+// ---- the ordered scatter of the drag reaction (DragScatter, sphx_internal.h) ------------------------
+__global__ __launch_bounds__(256) void drag_count_kernel(int n, int npad, int k, const int* __restrict__ nbr,
+                                                         const double* __restrict__ ptype, const int* __restrict__ qorder,
+                                                         int* cnt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int i = qorder ? qorder[p] : p;
+    for (int kk = 0; kk < k; ++kk) {
+        const int j = nbr[(size_t)kk * npad + p];
+        if (j >= 0 && j != i && ptype[j] == 2.0) atomicAdd(&cnt[j], 1);
+    }
+}
+// One WAVE per receiving particle (grid-stride): lane q holds entry q of the slice (a particle is a neighbour of a few
+// dozen others: one entry per lane nearly always), finds its rank by comparing its key with every other one (broadcast
+// lane by lane), parks its value at that rank in LDS, and lane 0 adds the parked values in order.  Slices longer than
+// 64 entries are added by lane 0 alone, smallest remaining key first.
+#define DRAG_RED_BLOCKS 2048
+#define DRAG_RED_U 4                      // entries per lane the wave form holds: slices up to 256 entries
+// the slice [s, s + L) added in key order -> (ax, ay, az), valid in lane 0
+template <int U>
+__device__ __forceinline__ void drag_slice_sum(int s, int L, const u64* __restrict__ keys, const double* __restrict__ vals,
+                                               double* pk, int lane, double& ax, double& ay, double& az) {
+    u64 key[U];
+    int rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = lane + 64 * u;
+        key[u] = q < L ? keys[s + q] : ~0ull;
+        rank[u] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < U; ++c) {
+        const int lc = L - 64 * c < 64 ? L - 64 * c : 64;
+        for (int t = 0; t < lc; ++t) {
+            const u64 kt = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(key[c] >> 32), t) << 32) |
+                           (u64)(unsigned)__builtin_amdgcn_readlane((int)key[c], t);
+#pragma unroll
+            for (int u = 0; u < U; ++u) rank[u] += kt < key[u] ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = lane + 64 * u;
+        if (q < L) {
+            const double* v = vals + 3 * (size_t)(s + q);
+            pk[3 * rank[u]] = v[0]; pk[3 * rank[u] + 1] = v[1]; pk[3 * rank[u] + 2] = v[2];
+        }
+    }
+    wave_sync();
+    if (lane == 0)
+        for (int t = 0; t < L; ++t) { ax += pk[3 * t]; ay += pk[3 * t + 1]; az += pk[3 * t + 2]; }
+    wave_sync();
+}
+// A wave takes 64 consecutive receivers at a time: every lane looks up one slice (most are empty: zeros written at once),
+// the non-empty ones are then added one after the other by the whole wave.
+__global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __restrict__ start, const u64* __restrict__ keys,
+                                                          const double* __restrict__ vals, double* react) {
+    __shared__ double parked[4][64 * DRAG_RED_U * 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* pk = parked[wave];
+    for (int j0 = (blockIdx.x * 4 + wave) * 64; j0 < n; j0 += gridDim.x * 4 * 64) {
+        const int jl = j0 + lane;
+        int sl = 0, Ll = 0;
+        if (jl < n) { sl = start[jl]; Ll = start[jl + 1] - sl; }
+        if (jl < n && Ll == 0) { react[3 * (size_t)jl] = 0.0; react[3 * (size_t)jl + 1] = 0.0; react[3 * (size_t)jl + 2] = 0.0; }
+        u64 todo = __builtin_amdgcn_ballot_w64(Ll > 0);
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int s = __builtin_amdgcn_readlane(sl, t), L = __builtin_amdgcn_readlane(Ll, t);
+            const int j = j0 + t;
+            double ax = 0.0, ay = 0.0, az = 0.0;
+            if (L <= 64) {
+                drag_slice_sum<1>(s, L, keys, vals, pk, lane, ax, ay, az);
+            } else if (L <= 64 * DRAG_RED_U) {
+                drag_slice_sum<DRAG_RED_U>(s, L, keys, vals, pk, lane, ax, ay, az);
+            } else if (lane == 0) {                       // a very long slice: smallest remaining key first, one lane
+                u64 last = 0;
+                bool have = false;
+                for (int tt = s; tt < s + L; ++tt) {
+                    u64 best = ~0ull;
+                    int bi = -1;
+                    for (int q = s; q < s + L; ++q) {
+                        const u64 kq = keys[q];
+                        if ((!have || kq > last) && kq < best) { best = kq; bi = q; }
+                    }
+                    ax += vals[3 * (size_t)bi]; ay += vals[3 * (size_t)bi + 1]; az += vals[3 * (size_t)bi + 2];
+                    last = best;
+                    have = true;
+                }
+            }
+            if (lane == 0) { react[3 * (size_t)j] = ax; react[3 * (size_t)j + 1] = ay; react[3 * (size_t)j + 2] = az; }
+        }
+    }
+}
+int sphx_drag_scatter_plan(sphx_ctx* ctx, int64_t n, int k, const int* nbr, const double* ptype, const int* qorder,
+                           DragScatter* out) {
+    const size_t cap0 = ctx->ds_cnt.cap;
+    SPHX_TRY(sphx_ensure(ctx, ctx->ds_cnt, ((size_t)n + 2) * sizeof(int)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->ds_start, ((size_t)n + 2) * sizeof(int)));
+    // (every reference could be to a dust particle: n k entries; memory is what this machine has)
+    SPHX_TRY(sphx_ensure(ctx, ctx->ds_keys, (size_t)n * k * sizeof(u64)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->ds_vals, (size_t)n * k * 3 * sizeof(double)));
+    if (ctx->ds_cnt.cap != cap0 || ctx->ds_cnt_zeroed != ctx->ds_cnt.p) {     // counted up here, back down by the fill
+        HIPCHK(hipMemsetAsync(ctx->ds_cnt.p, 0, ctx->ds_cnt.cap, ctx->stream));
+        ctx->ds_cnt_zeroed = ctx->ds_cnt.p;
+    }
+    hipLaunchKernelGGL(drag_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       (int)sphx_pad64(n), k, nbr, ptype, qorder, ctx->ds_cnt.as<int>());
+    HIPCHK(hipGetLastError());
+    SPHX_TRY(sphx_excl_scan_int(ctx, ctx->ds_cnt.as<int>(), ctx->ds_start.as<int>(), (int)n));
+    out->cnt = ctx->ds_cnt.as<int>(); out->start = ctx->ds_start.as<int>();
+    out->keys = ctx->ds_keys.as<u64>(); out->vals = ctx->ds_vals.as<double>();
+    return SPHX_OK;
+}
+int sphx_drag_scatter_reduce(sphx_ctx* ctx, int64_t n, const DragScatter& d, double* react) {
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(drag_reduce_kernel, dim3((unsigned)(want < DRAG_RED_BLOCKS ? want : DRAG_RED_BLOCKS)), dim3(256), 0,
+                       ctx->stream, (int)n, d.start, d.keys, d.vals, react);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 // ---- dust -> gas drag with scatter-added reaction          nsc:719-742 (net_impulse) --------------
 // Loop-form semantics inside the step loop: smoothing length of the dust neighbour (Weigh2_dust,
-// nsc:678), deltas relative to the particle itself.  The reaction is a scatter-add (float atomics):
-// with dust present the step is no longer bitwise reproducible, only to rounding.
+// nsc:678), deltas relative to the particle itself.  The reaction is an ORDERED scatter (DragScatter): the same bits
+// on every run, added in the reference's order (source particle by caller index, then list position).
 __global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, const int* __restrict__ nbr,
                                                         const RecB* __restrict__ recb,
                                                         const double* __restrict__ m,
                                                         const double* __restrict__ ptype,
                                                         const double* __restrict__ mgm,
                                                         const double* __restrict__ mcs,
-                                                        const int* __restrict__ qorder, double* onto,
-                                                        double* react) {
+                                                        const int* __restrict__ qorder, const int* __restrict__ id,
+                                                        double* onto, DragScatter sc) {
     const int p = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int i = qorder ? qorder[p] : p;
@@ -427,15 +551,17 @@ __global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, 
         const double q = ds2 - (dx * dx + dy * dy + dz * dz);
         const double ds4 = ds2 * ds2;
         const double wf = m[j] * 315.0 * (q * q * q) / (201.06192982974676 * (ds4 * ds4 * ds));   // nsc:678-681
-        if (!(wf > 0.0)) continue;
-        const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
-        const double coef = wf / mgm[j] * mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
-        const double fx = coef * dvx, fy = coef * dvy, fz = coef * dvz;
-        ox += fx; oy += fy; oz += fz;
-        if (j != i) {                                              // nsc:741
-            atomicAdd(&react[3 * (size_t)j], -fx);
-            atomicAdd(&react[3 * (size_t)j + 1], -fy);
-            atomicAdd(&react[3 * (size_t)j + 2], -fz);
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        if (wf > 0.0) {
+            const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
+            const double coef = wf / mgm[j] * mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
+            fx = coef * dvx; fy = coef * dvy; fz = coef * dvz;
+            ox += fx; oy += fy; oz += fz;
+        }
+        if (j != i) {                                              // nsc:741 (a zero where the kernel vanishes: counted too)
+            const int slot = sc.start[j] + atomicSub(&sc.cnt[j], 1) - 1;
+            sc.keys[slot] = ((u64)(unsigned)id[i] << 8) | (u64)kk;
+            sc.vals[3 * (size_t)slot] = -fx; sc.vals[3 * (size_t)slot + 1] = -fy; sc.vals[3 * (size_t)slot + 2] = -fz;
         }
     }
     onto[3 * (size_t)i] = ox; onto[3 * (size_t)i + 1] = oy; onto[3 * (size_t)i + 2] = oz;
@@ -445,12 +571,14 @@ int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const doubl
                    const double* mcs) {
     SPHX_TRY(sphx_ensure(ctx, ctx->drag_on, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->drag_re, (size_t)n * 3 * sizeof(double)));
-    HIPCHK(hipMemsetAsync(ctx->drag_re.p, 0, (size_t)n * 3 * sizeof(double), ctx->stream));
+    DragScatter sc;
+    SPHX_TRY(sphx_drag_scatter_plan(ctx, n, k, ctx->nbr.as<int>(), ptype, ctx->qorder, &sc));
     hipLaunchKernelGGL(pass_drag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(), m, ptype, mgm, mcs, ctx->qorder,
-                       ctx->drag_on.as<double>(), ctx->drag_re.as<double>());
+                       ctx->map_perm ? ctx->map_perm : ctx->st.id.as<int>(),       // the caller's index of a stored particle
+                       ctx->drag_on.as<double>(), sc);
     HIPCHK(hipGetLastError());
-    return SPHX_OK;
+    return sphx_drag_scatter_reduce(ctx, n, sc, ctx->drag_re.as<double>());
 }
 
 // ---- species pass: F[s,i] = sum_k Nw_j f_un[j,s] W       nsc:624-627 -------------------------
