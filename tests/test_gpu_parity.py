@@ -828,6 +828,33 @@ def test_grouped_search_equals_general_search(workload, n, K, steps, kw, monkeyp
             assert np.array_equal(res["grouped"][key], res[name][key], equal_nan=True), (name, key)
 
 
+@pytest.mark.parametrize("K", [1, 7, 40, 64])
+def test_hinted_search_on_a_lattice_with_exact_ties_and_coincident_particles(K):
+    """The step loop's hinted search (grouped kernel: fp32 distances, order certified or handed on) where nothing can be
+    certified by a margin: a cubic lattice (every shell of neighbours an exact tie) with a few hundred particles
+    duplicated in place.  The radii of the second and third step (hinted) must equal the exact K-th-neighbour distance
+    (cKDTree, eps = 0): with ties the index sets are not unique, the sorted distances are."""
+    from oracle import sph_oracle as orc
+    from sph_code_amd.sim import Simulation
+    import sph_code_amd.ics as ics
+    m = 28
+    ax = (np.arange(m) - (m - 1) / 2.0) * 1e16
+    pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).reshape(-1, 3)
+    rs = np.random.RandomState(3)
+    pts = np.ascontiguousarray(np.concatenate([pts, pts[rs.choice(len(pts), 300, replace=False)]]))     # coincident pairs
+    s0 = ics.WORKLOADS["uniform_cube"](len(pts))
+    s0["points"] = pts
+    s0["velocities"] = np.zeros_like(pts)
+    _, _, _, _, h_ref = orc.neighbors(pts, np.inf, K, eps=0.0)
+    sim = Simulation(s0, n_neigh=K)
+    for it in range(3):
+        sim.step(1, fixed_dt=1e-30)
+        d = sim.download()
+        assert np.array_equal(d["points"], pts), it                 # (a symmetric lattice at rest: nothing moves)
+        assert np.array_equal(d["sizes"], h_ref), (it, np.abs(d["sizes"] - h_ref).max())
+    assert sim.stats()["short_rows"] == 0
+
+
 @pytest.mark.parametrize("levels,distrust", [("1", "2"), ("2", "2"), ("0", "2"), ("1", "1"), ("0", "1")])
 def test_search_with_outlier_levels_is_exact_on_a_heavy_tailed_cloud(levels, distrust, monkeypatch):
     """A compact core with a halo of escapers spread over five decades in radius - what the reference's scheme leaves behind
