@@ -524,7 +524,12 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             SPHX_TRY(rc_);
             // (the blob order needs cell_of / perm / cell_start only: before the state is permuted, so that the
             //  deferred member sort has run when perm is used)
-            if (blob) SPHX_TRY(sphx_build_blob_order(ctx, n));
+            if (blob) {
+                ctx->defer_blob_scatter = true;          // (its last scatter: in sphx_permute_state's kernel, right below)
+                const int rc_b = sphx_build_blob_order(ctx, n);
+                ctx->defer_blob_scatter = false;
+                SPHX_TRY(rc_b);
+            }
         }
         const bool split_perm = ctx->split_perm && ctx->side_stream && !ctx->use_verlet;
         SPHX_TRY(sphx_permute_state(ctx, n, split_perm));

@@ -171,6 +171,7 @@ struct FusedCountArgs {
     unsigned* ticket;
     double* fin;
     u64* ct_reset;                          // "no crossing-time vote yet" for this step's pass 2 (nullable)
+    int* zero_int;                          // the search's fail-list counter, zeroed here instead of by a launch of its own (nullable)
 };
 __device__ __forceinline__ double nan_to_num_g(double v) {
     if (v != v) return 0.0;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(RED_BLOCK) void grid_count_fused(FusedCountArgs a) 
     double su[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
     const GridParams g = a.g;
     if (a.ct_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.ct_reset = SPHX_CT_NONE;
+    if (a.zero_int && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_int = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
         double v[3] = {a.x[i], a.y[i], a.z[i]};
         if (a.vx) {                                            // drv:233-238
@@ -492,6 +494,12 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         fa.hist = fill;
         fa.partial = part; fa.ticket = ticket; fa.fin = fin;
         fa.ct_reset = ctx->scal.as<u64>() + SC_CT_BITS;      // (read by the previous step's update, long done on this stream)
+        fa.zero_int = nullptr;
+        if (ctx->fail_list.p && ctx->fail_list.cap >= ((size_t)sphx_pad64(n) + 64) * sizeof(int)) {
+            fa.zero_int = ctx->fail_list.as<int>() + sphx_pad64(n);          // (where sphx_knn keeps the counter for this n)
+            ctx->fcount_zeroed = ctx->fail_list.p;
+            ctx->fcount_zeroed_n = n;
+        }
         ctx->ct_primed = true;
         int fb = pb < FUSED_MAXBLOCKS ? pb : FUSED_MAXBLOCKS;
         hipLaunchKernelGGL(grid_count_fused, dim3(fb), dim3(RED_BLOCK), 0, ctx->stream, fa);
@@ -610,43 +618,6 @@ int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const 
 // polytrope).  Otherwise (a very elongated or very fine grid): Morton code with the bits of (cx, cy, cz)
 // interleaved from the least significant end, each axis contributing only the bits it has, so the code
 // space is at most 8x the cell count whatever the grid's aspect ratio.
-struct BlobBits { int bx, by, bz; int hilbert; };
-__device__ __forceinline__ unsigned hilbert_rank(unsigned x, unsigned y, unsigned z, int b) {
-    // Skilling's transform (axes -> transposed Hilbert index), then the transposed bits interleaved
-    unsigned X[3] = {x, y, z};
-    const unsigned M = 1u << (b - 1);
-    for (unsigned Q = M; Q > 1; Q >>= 1) {
-        const unsigned P = Q - 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (X[i] & Q) X[0] ^= P;
-            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
-        }
-    }
-    X[1] ^= X[0]; X[2] ^= X[1];
-    unsigned t = 0;
-    for (unsigned Q = M; Q > 1; Q >>= 1)
-        if (X[2] & Q) t ^= Q - 1;
-    X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    unsigned out = 0;
-    for (int q = 0; q < b; ++q) {
-        out |= ((X[2] >> q) & 1u) << (3 * q);
-        out |= ((X[1] >> q) & 1u) << (3 * q + 1);
-        out |= ((X[0] >> q) & 1u) << (3 * q + 2);
-    }
-    return out;
-}
-__device__ __forceinline__ unsigned blob_rank(int cx, int cy, int cz, BlobBits b) {
-    if (b.hilbert) return hilbert_rank((unsigned)cx, (unsigned)cy, (unsigned)cz, b.hilbert);
-    unsigned out = 0;
-    int pos = 0;
-    for (int q = 0; q < 11; ++q) {
-        if (q < b.bx) out |= (unsigned)((cx >> q) & 1) << pos++;
-        if (q < b.by) out |= (unsigned)((cy >> q) & 1) << pos++;
-        if (q < b.bz) out |= (unsigned)((cz >> q) & 1) << pos++;
-    }
-    return out;
-}
 // one thread per cell; sort_perm != nullptr: also sorts the cell's members (cell_sort_members, deferred to here)
 __global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount,
                                                   int* sort_perm) {
@@ -711,9 +682,17 @@ int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
                        ctx->cell_start.as<int>(), mc, ctx->cells_unsorted ? ctx->perm.as<int>() : nullptr);
     ctx->cells_unsorted = false;
     SPHX_TRY(excl_scan_plus_total(ctx, mc, ms, M));
-    hipLaunchKernelGGL(blob_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, b,
-                       ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->cell_start.as<int>(), ms,
-                       ctx->porder.as<int>());
+    if (ctx->defer_blob_scatter) {
+        // the fused loop: the scatter rides in the kernel that permutes the state next (sphx_permute_state), one
+        // thread per stored particle there as here
+        ctx->blob_scatter_pending = true;
+        ctx->blob_scatter_bits = b;
+        ctx->blob_scatter_mstart = ms;
+    } else {
+        hipLaunchKernelGGL(blob_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, b,
+                           ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->cell_start.as<int>(), ms,
+                           ctx->porder.as<int>());
+    }
     HIPCHK(hipGetLastError());
     ctx->qorder = ctx->porder.as<int>();
     return SPHX_OK;

@@ -39,11 +39,20 @@ struct GatherArgs {
     double* dst[18];
     const int* id_src; int* id_dst; int* inv;
     const double* fun_src; double* fun_dst;
+    // the blob order's scatter (sphx_grid.hip blob_scatter) carried along: porder[...] = t  (bs_porder == nullptr: not)
+    GridParams bs_g; BlobBits bs_b;
+    const int *bs_cell_of, *bs_cell_start, *bs_mstart;
+    int* bs_porder;
 };
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const int p = a.perm[t];
+    if (a.bs_porder) {
+        const int c = a.bs_cell_of[p];
+        const int cx = c % a.bs_g.nx, cy = (c / a.bs_g.nx) % a.bs_g.ny, cz = c / (a.bs_g.nx * a.bs_g.ny);
+        a.bs_porder[a.bs_mstart[blob_rank(cx, cy, cz, a.bs_b)] + (t - a.bs_cell_start[c])] = t;
+    }
     for (int q = 0; q < a.narr; ++q) a.dst[q][t] = a.src[q][p];
     if (a.id_src) {
         const int id = a.id_src[p];
@@ -69,6 +78,13 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split) {
     DevBuf* dst[] = {&b.x, &b.y, &b.z, &b.hprev, &b.vx, &b.vy, &b.vz, &b.ax, &b.ay, &b.az,
                      &b.m, &b.T, &b.mu, &b.gam, &b.E, &b.ptype};
     GatherArgs g;
+    g.bs_porder = nullptr;
+    if (ctx->blob_scatter_pending) {
+        g.bs_g = ctx->grid; g.bs_b = ctx->blob_scatter_bits;
+        g.bs_cell_of = ctx->cell_of.as<int>(); g.bs_cell_start = ctx->cell_start.as<int>();
+        g.bs_mstart = ctx->blob_scatter_mstart; g.bs_porder = ctx->porder.as<int>();
+        ctx->blob_scatter_pending = false;
+    }
     g.n = (int)n; g.narr = 16; g.s = ctx->sp;
     g.perm = ctx->perm.as<int>();
     for (int q = 0; q < 16; ++q) {
@@ -97,6 +113,7 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split) {
         rest.narr = g.narr - 4;
         for (int q = 0; q < rest.narr; ++q) { rest.src[q] = g.src[q + 4]; rest.dst[q] = g.dst[q + 4]; }
         rest.id_src = nullptr;
+        rest.bs_porder = nullptr;
         g.narr = 4;
         g.fun_src = nullptr; g.fun_dst = nullptr;
     }

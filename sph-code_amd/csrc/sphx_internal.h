@@ -82,6 +82,46 @@ __device__ __forceinline__ bool sphx_outside_box(const GridParams& g, double x, 
     return tx < 0.0 || tx >= (double)g.nx || ty < 0.0 || ty >= (double)g.ny || tz < 0.0 || tz >= (double)g.nz;
 }
 
+// ---- blob order: the rank of a cell along the space-filling curve (sphx_grid.hip builds the order; the kernel that
+// permutes the state, sphx_integrate.hip, can carry its last scatter) ----
+struct BlobBits { int bx, by, bz; int hilbert; };
+__device__ __forceinline__ unsigned hilbert_rank(unsigned x, unsigned y, unsigned z, int b) {
+    // Skilling's transform (axes -> transposed Hilbert index), then the transposed bits interleaved
+    unsigned X[3] = {x, y, z};
+    const unsigned M = 1u << (b - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    unsigned out = 0;
+    for (int q = 0; q < b; ++q) {
+        out |= ((X[2] >> q) & 1u) << (3 * q);
+        out |= ((X[1] >> q) & 1u) << (3 * q + 1);
+        out |= ((X[0] >> q) & 1u) << (3 * q + 2);
+    }
+    return out;
+}
+__device__ __forceinline__ unsigned blob_rank(int cx, int cy, int cz, BlobBits b) {
+    if (b.hilbert) return hilbert_rank((unsigned)cx, (unsigned)cy, (unsigned)cz, b.hilbert);
+    unsigned out = 0;
+    int pos = 0;
+    for (int q = 0; q < 11; ++q) {
+        if (q < b.bx) out |= (unsigned)((cx >> q) & 1) << pos++;
+        if (q < b.by) out |= (unsigned)((cy >> q) & 1) << pos++;
+        if (q < b.bz) out |= (unsigned)((cz >> q) & 1) << pos++;
+    }
+    return out;
+}
+
 // device-resident particle state, structure of arrays (one set; `alt` is the permute target)
 struct StateArrays {
     DevBuf x, y, z, vx, vy, vz, ax, ay, az;      // position, velocity, previous total accel
@@ -156,6 +196,9 @@ struct sphx_ctx {
     double *clamp_vx = nullptr, *clamp_vy = nullptr, *clamp_vz = nullptr;   // set by the step: the grid build applies drv:233-238
     bool bbox_ticket_zeroed = false;
     bool defer_cell_sort = false, cells_unsorted = false;   // the per-cell member sort rides in the blob-order pass
+    bool defer_blob_scatter = false, blob_scatter_pending = false;   // the blob order's last scatter rides in the state's permutation
+    BlobBits blob_scatter_bits;
+    const int* blob_scatter_mstart = nullptr;
     bool species_lds = true;        // SPHX_SPECIES_LDS=0: the species pass by gathers (sphx_sums.hip) also when blob lists exist
     bool split_perm = true;         // SPHX_SPLIT_PERM=0: the whole state permuted in one launch before the search
     bool use_group = true;          // hinted searches by the lane-per-query grouped kernel (SPHX_KNN_GROUP=0: off)
@@ -171,6 +214,8 @@ struct sphx_ctx {
     bool olev_ev_valid = false;
     u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
     int64_t farq_last = 0;          // far queries met by the previous hinted search
+    const void* fcount_zeroed = nullptr;   // the fail-list allocation whose counter the grid build has zeroed for this step
+    int64_t fcount_zeroed_n = 0;
     int64_t list_len_last = 0;      // queries the previous hinted search left to the general kernel (sizes the list-mode grid)
     bool knn_lag_external = false;  // the caller copies SC_NFAILQ .. SC_BADHINT out behind the search and hands them back
     bool knn_lag_valid = false;

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
         if (nshort) atomicAdd(&a.counters[SC_SHORT], nshort);
         if (nfar) atomicAdd(&a.counters[SC_FARQ], nfar);
         if (nbad) atomicAdd(&a.counters[SC_BADHINT], nbad);
+        if (LIST && blockIdx.x == 0 && threadIdx.x == 0) a.counters[SC_NFAILQ] = (u64)(u32)total;      // this search's list length
 #ifdef SPHX_KNN_PROF
         for (int pc = 0; pc < 2; ++pc)
             if (p_n[pc]) {
@@ -796,7 +797,9 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             SPHX_TRY(sphx_ensure(ctx, ctx->fail_list, ((size_t)a.npad + 64) * sizeof(int)));
             int* flist = ctx->fail_list.as<int>();
             int* fcount = flist + a.npad;
-            HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
+            if (!(ctx->fcount_zeroed == ctx->fail_list.p && ctx->fcount_zeroed_n == n))     // (else: the grid build's first kernel did it)
+                HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
+            ctx->fcount_zeroed = nullptr;
             KnnGroupArgs ga;
             ga.n = a.n; ga.k = a.k; ga.npad = a.npad; ga.n_active = a.n_active;
             ga.x = a.x; ga.y = a.y; ga.z = a.z; ga.id = a.id; ga.qorder = a.qorder; ga.cell_start = a.cell_start;
@@ -816,7 +819,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
                 else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(ctx->scal.as<u64>() + SC_NFAILQ, fcount, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            // (SC_NFAILQ is written by the list-mode launch itself)
         }
         if (lagged && !ext) {
             if (!ctx->olev_ev) HIPCHK(hipEventCreateWithFlags(&ctx->olev_ev, hipEventDisableTiming));
