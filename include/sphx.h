@@ -76,6 +76,7 @@ typedef struct sphx_stats {
     double  ms_species;    /* species pass of the step (+ metallicity, AGB yields); ms_density excludes it */
     int64_t short_rows;    /* searches that gave up after the last radius of the retry ladder with fewer than K
                               neighbours although more particles exist (pathological states only; 0 otherwise) */
+    int64_t detail_steps;  /* steps accumulated in ms_prep .. ms_integrate, ms_gravity, ms_species (sphx_set_timing_detail) */
     int64_t far_queries;   /* last hinted search but one: queries outside the grid box with a search sphere wider than 8 cells */
     int64_t outlier_levels;/* last hinted search: nested outlier levels it was given (0: none built) */
 } sphx_stats;
@@ -97,6 +98,10 @@ int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
  * rscale * h_previous (default 1.2) and bins particles into cells of edge
  * cell_factor * mean(h) (default 0.6).  Values <= 0 keep the current setting. */
 int         sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor);
+/* sphx_step times the step (ms_total) and the search's launches (ms_grid, ms_search) with HIP events always; one event per
+ * pass (ms_prep ... ms_integrate, ms_gravity, ms_species; stats.detail_steps counts the steps they cover) only when asked:
+ * an event record between two dependent kernels costs the stream ~10 us.  Off by default (SPHX_TIMING_DETAIL=1: on). */
+int         sphx_set_timing_detail(sphx_ctx* ctx, int on);
 /* Incremental search (off by default).  With verlet != 0 a full search also keeps each
  * particle's 64 nearest candidates; following steps take the exact kNN from those lists as long
  * as it can be PROVEN exact from the displacements since (sphx_refresh.hip), else the step

@@ -23,7 +23,7 @@ class SphxStats(C.Structure):
                [(n, C.c_int64) for n in ("n", "steps", "candidates", "retries", "cells", "refresh_steps",
                                          "rebuild_steps")] + \
                [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64),
-                ("ms_species", C.c_double), ("short_rows", C.c_int64), ("far_queries", C.c_int64),
+                ("ms_species", C.c_double), ("short_rows", C.c_int64), ("detail_steps", C.c_int64), ("far_queries", C.c_int64),
                 ("outlier_levels", C.c_int64)]
 
     def as_dict(self):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "sphx_dev_need_map": (C.c_int, [_P, C.c_int64, _P, _P, C.POINTER(C.c_double), C.c_double, C.c_int, _P]),
     "sphx_dev_integrate_auto": (C.c_int, [_P, C.c_int64] + [_P] * 13 + [C.c_int, C.c_double, _P]),
     "sphx_dev_reach": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, _P]),
+    "sphx_set_timing_detail": (C.c_int, [_P, C.c_int]),
     "sphx_dev_reach_dt": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
     "sphx_dev_plan_mask": (C.c_int, [_P, C.c_int64, _P, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "sphx_dev_step_scalars": (C.c_int, [_P, C.c_int64, _P, _P, C.c_double, C.c_double, _P, _P]),
@@ -258,6 +259,10 @@ class Context:
 
     def reset_stats(self):
         self.check(self.lib.sphx_reset_stats(self.h))
+
+    def set_timing_detail(self, on=True):
+        """Per-pass timing events in sphx_step (ms_prep ... ms_integrate); off by default: each costs the stream ~10 us."""
+        self.check(self.lib.sphx_set_timing_detail(self.h, 1 if on else 0))
 
 
 _default = None

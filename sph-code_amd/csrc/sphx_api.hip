@@ -85,6 +85,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
@@ -457,6 +458,11 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     const int64_t n = ctx->n;
     const int ring = (int)(ctx->step_count % 3);
     hipEvent_t* ev = ctx->evring[ring];
+    // Timing events: around the step and around the search always (the bench's roofline needs the search's launch time);
+    // one per pass only on request (sphx_set_timing_detail / SPHX_TIMING_DETAIL=1) - an event record between two
+    // dependent kernels costs the stream ~10 us, six of them 4 % of a 1.5 ms step.
+    const bool detail = ctx->timing_detail;
+    ctx->ev_detail[ring] = detail;
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
@@ -597,12 +603,12 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                                s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
                                s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(), s.gam.as<double>(),
                                s.ptype.as<double>()));
-        HIPCHK(hipEventRecord(ev[3], ctx->stream));
+        if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
         SPHX_TRY(sphx_loop_step_sums(ctx, n, k, ctx->loop_d));
-        HIPCHK(hipEventRecord(ev[9], ctx->stream));
+        if (detail) HIPCHK(hipEventRecord(ev[9], ctx->stream));
         if (species) SPHX_TRY(sphx_step_species(ctx, n, k));       // nsc:624-627 (+ metallicity, AGB yields)
-        HIPCHK(hipEventRecord(ev[4], ctx->stream));
-        HIPCHK(hipEventRecord(ev[5], ctx->stream));
+        if (detail) HIPCHK(hipEventRecord(ev[4], ctx->stream));
+        if (detail) HIPCHK(hipEventRecord(ev[5], ctx->stream));
         if (ctx->drag)
             SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                     s.mcs.as<double>()));
@@ -624,20 +630,20 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     }
-    HIPCHK(hipEventRecord(ev[3], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
     SPHX_TRY(sphx_pass_density(ctx, n, k));
-    HIPCHK(hipEventRecord(ev[9], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[9], ctx->stream));
     // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un
     if (ctx->s > 0 && ctx->st.fun.p) SPHX_TRY(sphx_step_species(ctx, n, k));
-    HIPCHK(hipEventRecord(ev[4], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[4], ctx->stream));
     SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
-    HIPCHK(hipEventRecord(ev[5], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[5], ctx->stream));
     SPHX_TRY(sphx_pass_visc(ctx, n, k, s.m.as<double>()));
     if (ctx->drag)
         SPHX_TRY(sphx_pass_drag(ctx, n, k, s.m.as<double>(), s.ptype.as<double>(), s.mgm.as<double>(),
                                 s.mcs.as<double>()));
     }
-    HIPCHK(hipEventRecord(ev[6], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[6], ctx->stream));
     if (ctx->gravity) {                          // drv:448-449; softening = median(h), nsc:358
         SPHX_TRY(sphx_ensure(ctx, ctx->grav, (size_t)n * 3 * sizeof(double)));
         double* eps = ctx->scal.as<double>() + SC_GRAV_EPS;
@@ -650,7 +656,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                                               s.m.as<double>(), ctx->grav_ws, eps, 0.0, ctx->grav_G, nullptr,
                                               ctx->grav.as<double>()));
     }
-    HIPCHK(hipEventRecord(ev[8], ctx->stream));
+    if (detail) HIPCHK(hipEventRecord(ev[8], ctx->stream));
     // (dt by drv:222-229 inside the update kernel; the crossing-time vote is reset by the next step's first kernel, or
     //  primed by its pass 2 when that grid build is not the fused one)
     SPHX_TRY(sphx_integrate(ctx, n, 1, first, fixed_dt));
@@ -664,12 +670,18 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
     ctx->ev_pending &= ~(1u << ring);
     hipEvent_t* ev = ctx->evring[ring];
     HIPCHK(hipEventSynchronize(ev[7]));
-    float ms[7];
-    for (int i = 0; i < 7; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     float tot;
     HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[7]));
     sphx_stats& st = ctx->stats;
-    st.ms_grid += ms[0]; st.ms_search += ms[1]; st.ms_prep += ms[2]; st.ms_density += ms[3];
+    float ms[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
+    st.ms_grid += ms[0]; st.ms_search += ms[1]; st.ms_total += tot;
+    st.steps += 1;
+    st.n = ctx->n;
+    if (!ctx->ev_detail[ring]) return SPHX_OK;    // (the per-pass events were not recorded for this step)
+    for (int i = 2; i < 6; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    st.ms_prep += ms[2];
     float mg = 0.f, mi = 0.f;
     HIPCHK(hipEventElapsedTime(&mg, ev[6], ev[8]));
     HIPCHK(hipEventElapsedTime(&mi, ev[8], ev[7]));
@@ -682,9 +694,8 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
         ms[3] = md;
         st.ms_species += msp;
     }
-    st.ms_pi += ms[4]; st.ms_visc += ms[5]; st.ms_integrate += ms[6]; st.ms_total += tot;
-    st.steps += 1;
-    st.n = ctx->n;
+    st.ms_density += ms[3]; st.ms_pi += ms[4]; st.ms_visc += ms[5]; st.ms_integrate += ms[6];
+    st.detail_steps += 1;
     return SPHX_OK;
 }
 
@@ -880,6 +891,12 @@ extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
     *out = ctx->stats;
     return SPHX_OK;
 }
+extern "C" int sphx_set_timing_detail(sphx_ctx* ctx, int on) {
+    if (!ctx) return SPHX_E_ARG;
+    ctx->timing_detail = on != 0;
+    return SPHX_OK;
+}
+
 extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
     if (!ctx) return SPHX_E_ARG;
     SPHX_TRY(sphx_dev_collect(ctx));

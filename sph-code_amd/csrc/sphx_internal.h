@@ -275,6 +275,8 @@ struct sphx_ctx {
     int exp_knn = -1, exp_blob = 0, exp_pass = -1;
     size_t exp_blob_lds = 0;
     hipEvent_t evring[3][10] = {{nullptr}};
+    bool timing_detail = false;         // per-pass timing events in sphx_step (sphx_set_timing_detail)
+    bool ev_detail[3] = {false, false, false};
     unsigned ev_pending = 0;            // bit s: ring slot s holds an uncollected step
     hipEvent_t lag_bev[2] = {nullptr, nullptr}, lag_hev[2] = {nullptr, nullptr};
     bool lag_on = false;                // set by the fused loop around its grid build

@@ -73,6 +73,8 @@ def test_gpu_step_with_gravity_vs_oracle():
     Gbig = 3e7 * orc.G_NEWTON          # this light test cloud would hardly feel its own gravity otherwise
     sim = Simulation(s0, n_neigh=K, gravity="direct", G=Gbig)
     plain = Simulation(s0, n_neigh=K)
+    sim.ctx.set_timing_detail(True)          # (per-pass timing events: ms_gravity below)
+    plain.ctx.set_timing_detail(True)
     ref = dict(s0)
     for it in range(nsteps):
         sim.step(1)
@@ -132,6 +134,7 @@ def test_gpu_step_tree_gravity_tracks_direct():
     a = Simulation(s0, n_neigh=40, gravity="direct", G=Gbig)
     b = Simulation(s0, n_neigh=40, gravity="tree", G=Gbig)
     c = Simulation(s0, n_neigh=40)
+    b.ctx.set_timing_detail(True)
     for sim in (a, b, c):
         sim.step(3)
     ra, rb, rc = a.download(), b.download(), c.download()

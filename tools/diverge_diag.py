@@ -18,6 +18,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 s0 = ics.WORKLOADS[wl](n)
 sim = Simulation(s0, n_neigh=40)
+sim.ctx.set_timing_detail(True)
 q = [50, 90, 99, 99.9, 100]
 for it in range(steps):
     sim.reset_stats()
