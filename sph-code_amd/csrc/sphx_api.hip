@@ -499,7 +499,8 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             const double* hs;                                                  // [0] sum ... [3] count
             if (ctx->lag_hvalid[ctx->lag_hslot]) {
                 // copied out right after the previous step's search: no wait on that step's tail
-                HIPCHK(hipEventSynchronize(ctx->lag_hev[ctx->lag_hslot]));
+                HIPCHK(hipEventSynchronize(ctx->lag_halias[ctx->lag_hslot] ? ctx->lag_halias[ctx->lag_hslot]
+                                                                             : ctx->lag_hev[ctx->lag_hslot]));
                 hs = (const double*)((char*)ctx->pinned + LAG_OFF + 512 * ctx->lag_hslot + 256);
             } else {
                 HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 256, ctx->scal.as<double>() + SC_HSUM, 4 * sizeof(double),
@@ -522,9 +523,11 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             StateArrays& r = ctx->st;       // the box statistics are the previous step's when there are any
             const bool blob = ctx->use_blob && !ctx->use_verlet;
             ctx->lag_on = true;
+            ctx->step_ev1 = ev[1];            // (recorded below, behind the state's permutation)
             ctx->defer_cell_sort = blob;      // the blob-order pass over the cells sorts their members too
             const int rc_ = sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint);
             ctx->lag_on = false;
+            ctx->step_ev1 = nullptr;
             ctx->defer_cell_sort = false;
             ctx->clamp_vx = nullptr;
             SPHX_TRY(rc_);
@@ -538,8 +541,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             }
         }
         const bool split_perm = ctx->split_perm && ctx->side_stream && !ctx->use_verlet;
-        SPHX_TRY(sphx_permute_state(ctx, n, split_perm));
-        HIPCHK(hipEventRecord(ev[1], ctx->stream));
+        SPHX_TRY(sphx_permute_state(ctx, n, split_perm, ev[1]));      // (records ev[1] behind the search's part)
         StateArrays& r = ctx->st;
         KnnOut o;
         o.nbr = ctx->nbr.as<int>();
@@ -577,8 +579,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
     hipStream_t hs_stream = ctx->stream;
     if (fork) {
-        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ev[2], 0));       // (the search's end event doubles as the fork)
         hs_stream = ctx->side_stream;
     }
     {
@@ -590,7 +591,12 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
                               (SC_BADHINT - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
-        HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
+        if (fork) {
+            ctx->lag_halias[hsl] = ctx->ev_join;          // recorded below on the side stream, behind the record build
+        } else {
+            HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
+            ctx->lag_halias[hsl] = nullptr;
+        }
         ctx->lag_hvalid[hsl] = true;
         ctx->lag_hslot = hsl;
     }
@@ -615,10 +621,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     } else {
     {
         hipStream_t main_stream = ctx->stream;
-        if (fork) {
-            HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-            ctx->stream = ctx->side_stream;
-        }
+        if (fork) ctx->stream = ctx->side_stream;          // (it is already behind the search: the h sums went there first)
         const int rc_prep = sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
                                       s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr,
                                       s.m.as<double>(), s.hprev.as<double>(), s.T.as<double>(), s.mu.as<double>(),

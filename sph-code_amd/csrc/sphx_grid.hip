@@ -378,8 +378,9 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
             if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
             SPHX_TRY(bbox_launch(ctx, n, x, y, z, true, slot + 512 * cur));
             HIPCHK(hipEventRecord(ctx->lag_bev[cur], ctx->stream));
+            ctx->lag_balias[cur] = nullptr;
         }
-        HIPCHK(hipEventSynchronize(ctx->lag_bev[use]));
+        HIPCHK(hipEventSynchronize(ctx->lag_balias[use] ? ctx->lag_balias[use] : ctx->lag_bev[use]));
         bbox_finish(slot + 512 * use, bb);
         ctx->lag_bvalid[cur] = true;
         ctx->lag_bn[cur] = n;
@@ -508,7 +509,12 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         ctx->clamp_vx = nullptr;
         char* slot = (char*)ctx->pinned + LAG_OFF;
         HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipEventRecord(ctx->lag_bev[lag_cur], ctx->stream));
+        if (ctx->step_ev1) {
+            ctx->lag_balias[lag_cur] = ctx->step_ev1;          // recorded by the caller a few launches on, before the search
+        } else {
+            HIPCHK(hipEventRecord(ctx->lag_bev[lag_cur], ctx->stream));
+            ctx->lag_balias[lag_cur] = nullptr;
+        }
     } else {
         hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
                            ctx->cell_of.as<int>(), fill);

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
 // split = true (the fused loop, a side stream at hand): what the search reads - positions, previous radii, ids - is
 // permuted on the main stream, everything else on the side stream beside the search (which is bound by instruction
 // issue and leaves the memory system idle); the caller makes the main stream wait for ctx->ev_perm before it reads those.
-int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split) {
+// after_first: an event the caller wants recorded behind the first launch (its search-timing start): doubles as the fork.
+int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split, hipEvent_t after_first) {
     StateArrays& a = ctx->st;
     StateArrays& b = ctx->alt;
     // (the search's arrays first)
@@ -118,10 +119,12 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split) {
         g.fun_src = nullptr; g.fun_dst = nullptr;
     }
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g);
+    if (after_first) HIPCHK(hipEventRecord(after_first, ctx->stream));
     if (split) {
         // (behind the search's part, not beside it: both are bound by the same memory system)
-        HIPCHK(hipEventRecord(ctx->ev_perm_fork, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_perm_fork, 0));
+        hipEvent_t fork_ev = after_first ? after_first : ctx->ev_perm_fork;
+        if (!after_first) HIPCHK(hipEventRecord(fork_ev, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->side_stream, fork_ev, 0));
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->side_stream, rest);
         HIPCHK(hipEventRecord(ctx->ev_perm, ctx->side_stream));
     }

@@ -279,6 +279,11 @@ struct sphx_ctx {
     bool ev_detail[3] = {false, false, false};
     unsigned ev_pending = 0;            // bit s: ring slot s holds an uncollected step
     hipEvent_t lag_bev[2] = {nullptr, nullptr}, lag_hev[2] = {nullptr, nullptr};
+    // An event record costs the stream ~10 us: where the fused loop records one anyway right behind a read-back's copy
+    // (the search's start event behind the box statistics, the side stream's join event behind the h sums), the host
+    // waits on that one instead of a record of its own (the alias; nullptr: lag_bev / lag_hev were recorded).
+    hipEvent_t lag_balias[2] = {nullptr, nullptr}, lag_halias[2] = {nullptr, nullptr};
+    hipEvent_t step_ev1 = nullptr;      // set by the fused loop around its grid build: the event it records before the search
     bool lag_on = false;                // set by the fused loop around its grid build
     bool lag_bvalid[2] = {false, false}, lag_hvalid[2] = {false, false};
     int64_t lag_bn[2] = {0, 0};
@@ -409,7 +414,7 @@ int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmaj
 
 // integrate / layout helpers (sphx_integrate.hip)
 int sphx_clamp(sphx_ctx* ctx, int64_t n, StateArrays& s);
-int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split = false);
+int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split = false, hipEvent_t after_first = nullptr);
 int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h);
 int sphx_compute_dt(sphx_ctx* ctx, int first, double fixed_dt);
 int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt = 0, int first = 0, double fixed_dt = 0.0);
