@@ -582,7 +582,9 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         HIPCHK(hipStreamWaitEvent(ctx->side_stream, ev[2], 0));       // (the search's end event doubles as the fork)
         hs_stream = ctx->side_stream;
     }
-    {
+    // (forked: BEHIND the record build on the side stream - the passes wait for that one, not for this; nobody but the
+    //  next step's host code reads the sums)
+    auto h_sums_out = [&]() -> int {
         hipStream_t main_stream = ctx->stream;
         ctx->stream = hs_stream;
         const int rc_h = sphx_hsum(ctx, n, s.hprev.as<double>());
@@ -591,15 +593,13 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
                               (SC_BADHINT - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
-        if (fork) {
-            ctx->lag_halias[hsl] = ctx->ev_join;          // recorded below on the side stream, behind the record build
-        } else {
-            HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
-            ctx->lag_halias[hsl] = nullptr;
-        }
+        HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
+        ctx->lag_halias[hsl] = nullptr;
         ctx->lag_hvalid[hsl] = true;
         ctx->lag_hslot = hsl;
-    }
+        return SPHX_OK;
+    };
+    if (!fork) SPHX_TRY(h_sums_out());
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
@@ -631,6 +631,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         if (fork) {
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            SPHX_TRY(h_sums_out());
         }
     }
     if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
