@@ -98,9 +98,9 @@ int         sphx_get_constants(const sphx_ctx* ctx, sphx_constants* c);
  * rscale * h_previous (default 1.2) and bins particles into cells of edge
  * cell_factor * mean(h) (default 0.6).  Values <= 0 keep the current setting. */
 int         sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor);
-/* sphx_step times the step (ms_total) and the search's launches (ms_grid, ms_search) with HIP events always; one event per
- * pass (ms_prep ... ms_integrate, ms_gravity, ms_species; stats.detail_steps counts the steps they cover) only when asked:
- * an event record between two dependent kernels costs the stream ~10 us.  Off by default (SPHX_TIMING_DETAIL=1: on). */
+/* sphx_step times the whole call (ms_total) and every step's search launches (ms_search) with HIP events always; one event
+ * per pass (ms_grid, ms_prep ... ms_integrate, ms_gravity, ms_species; stats.detail_steps counts the steps they cover) only
+ * when asked: an event record between two dependent kernels costs the stream ~10 us.  Off by default (SPHX_TIMING_DETAIL=1). */
 int         sphx_set_timing_detail(sphx_ctx* ctx, int on);
 /* Incremental search (off by default).  With verlet != 0 a full search also keeps each
  * particle's 64 nearest candidates; following steps take the exact kNN from those lists as long

@@ -454,7 +454,8 @@ extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
     return SPHX_OK;
 }
 
-static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_dt) {
+// call_first / call_last: the first / last step of this sphx_step call (they carry the call's start and end events)
+static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_dt, bool call_first, bool call_last) {
     const int64_t n = ctx->n;
     const int ring = (int)(ctx->step_count % 3);
     hipEvent_t* ev = ctx->evring[ring];
@@ -463,11 +464,15 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     // dependent kernels costs the stream ~10 us, six of them 4 % of a 1.5 ms step.
     const bool detail = ctx->timing_detail;
     ctx->ev_detail[ring] = detail;
+    // (the step's own start and end events likewise: without them the call's first and last step bracket the call,
+    //  whose time is then shared out over its steps)
+    const bool rec0 = detail || call_first, rec7 = detail || call_last;
+    ctx->ev_has07[ring] = (rec0 ? 1 : 0) | (rec7 ? 2 : 0);
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
     ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
-    HIPCHK(hipEventRecord(ev[0], ctx->stream));
+    if (rec0) HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238: applied by the grid build's first pass over the particles (sphx_grid.hip); the Verlet path looks at
     // the positions before any grid is built, so it clamps here
     ctx->clamp_vx = nullptr;
@@ -664,7 +669,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     // (dt by drv:222-229 inside the update kernel; the crossing-time vote is reset by the next step's first kernel, or
     //  primed by its pass 2 when that grid build is not the fused one)
     SPHX_TRY(sphx_integrate(ctx, n, 1, first, fixed_dt));
-    HIPCHK(hipEventRecord(ev[7], ctx->stream));
+    if (rec7) HIPCHK(hipEventRecord(ev[7], ctx->stream));
     ctx->step_count++;
     return SPHX_OK;
 }
@@ -673,17 +678,19 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
     if (!(ctx->ev_pending & (1u << ring))) return SPHX_OK;
     ctx->ev_pending &= ~(1u << ring);
     hipEvent_t* ev = ctx->evring[ring];
-    HIPCHK(hipEventSynchronize(ev[7]));
-    float tot;
-    HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[7]));
+    const int has = ctx->ev_has07[ring];
+    HIPCHK(hipEventSynchronize((has & 2) ? ev[7] : ev[2]));
     sphx_stats& st = ctx->stats;
     float ms[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
     HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
-    st.ms_grid += ms[0]; st.ms_search += ms[1]; st.ms_total += tot;
+    st.ms_search += ms[1];
     st.steps += 1;
     st.n = ctx->n;
-    if (!ctx->ev_detail[ring]) return SPHX_OK;    // (the per-pass events were not recorded for this step)
+    if (!ctx->ev_detail[ring]) return SPHX_OK;    // (only the search's events were recorded for this step; ms_total: per call)
+    float tot;
+    HIPCHK(hipEventElapsedTime(&tot, ev[0], ev[7]));
+    HIPCHK(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    st.ms_grid += ms[0]; st.ms_total += tot;
     for (int i = 2; i < 6; ++i) HIPCHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     st.ms_prep += ms[2];
     float mg = 0.f, mi = 0.f;
@@ -711,16 +718,25 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     HIPCHK(hipSetDevice(ctx->device));
     if (!(dist > 0.0) || !isfinite(dist)) dist = 0.0;
     ctx->k = k;
+    hipEvent_t call_start = nullptr, call_end = nullptr;
+    const bool per_call = !ctx->timing_detail;             // (else every step times itself)
     for (int it = 0; it < nsteps; ++it) {
         const int ring = (int)(ctx->step_count % 3);
         SPHX_TRY(collect_stats(ctx, ring));            // (the step launched three steps ago, if still uncollected)
-        SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt));
+        if (it == 0) call_start = ctx->evring[ring][0];
+        if (it == nsteps - 1) call_end = ctx->evring[ring][7];
+        SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt, it == 0, it == nsteps - 1));
         ctx->ev_pending |= 1u << ring;
         SPHX_TRY(collect_stats(ctx, (ring + 1) % 3));  // two steps ago: finished long since, no wait
     }
     HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->scal.p, SC_NSLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int r = 0; r < 3; ++r) SPHX_TRY(collect_stats(ctx, (int)((ctx->step_count + r) % 3)));   // oldest first
+    if (per_call && call_start && call_end) {              // the call's wall time on the stream, over all its steps
+        float tot = 0.f;
+        HIPCHK(hipEventElapsedTime(&tot, call_start, call_end));
+        ctx->stats.ms_total += tot;
+    }
     const u64* sc = (const u64*)ctx->pinned;
     ctx->dt_last = ((const double*)ctx->pinned)[SC_DT];
     ctx->stats.candidates = (int64_t)sc[SC_CAND];

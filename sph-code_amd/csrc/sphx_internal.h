@@ -277,6 +277,7 @@ struct sphx_ctx {
     hipEvent_t evring[3][10] = {{nullptr}};
     bool timing_detail = false;         // per-pass timing events in sphx_step (sphx_set_timing_detail)
     bool ev_detail[3] = {false, false, false};
+    int ev_has07[3] = {0, 0, 0};        // bit 0 / 1: the slot's step recorded its start / end event
     unsigned ev_pending = 0;            // bit s: ring slot s holds an uncollected step
     hipEvent_t lag_bev[2] = {nullptr, nullptr}, lag_hev[2] = {nullptr, nullptr};
     // An event record costs the stream ~10 us: where the fused loop records one anyway right behind a read-back's copy
