@@ -599,9 +599,10 @@ extern "C" int sphx_dev_regroup(sphx_ctx* ctx, int64_t n_sel, const int64_t* sel
 // floor(w_i / cs) + 1 cells (Chebyshev) of the cell holding an owned particle i claiming reach w_i:
 // a superset of the cells from which a point can lie within w_i of particle i.  One thread per
 // particle writes its cube (27 bytes for nearly all; racing stores of the same value).
+// Claims wider than rwide cells are not walked here: they go into wide0 (the widest per cell) for the target-side pass below.
 __global__ __launch_bounds__(256) void need_map_kernel(long long n, const double* pos, const double* w, double lx,
                                                        double ly, double lz, double cs, int G,
-                                                       unsigned char* out) {
+                                                       unsigned char* out, int rwide, u64* wide0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double wi = w[i];
@@ -615,6 +616,10 @@ __global__ __launch_bounds__(256) void need_map_kernel(long long n, const double
     const double q = wi / cs;
     const double rr = floor(q) + 1.0;
     const int r = rr < (double)G ? (int)rr : G;
+    if (r > rwide) {
+        atomicMax(&wide0[((size_t)cz * G + cy) * G + cx], (u64)__double_as_longlong(wi));     // (positive doubles order like their bits)
+        return;
+    }
     const double q2 = q * q;                       // (inf for an overflowing reach: everything is claimed)
     const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
@@ -637,17 +642,107 @@ __global__ __launch_bounds__(256) void need_map_kernel(long long n, const double
     }
 }
 
+// The same map for any mix of claims at a bounded cost.  The kernel above walks, for every owned particle, the whole cube
+// of cells around it: fine for claims of a few cells, but an expanding cloud's rim claims spheres 50+ cells wide -
+// (2r+1)^3 cells each, one thread per particle, thousands of them overlapping: 43 ms for 5000 such claims at G = 96
+// (measured) where the whole map has 885 k cells.  So claims wider than NM_RWIDE cells are marked from the TARGET side:
+// (1) the widest such claim per cell (the rule is monotone in w: a cell's widest claim stands for all its particles),
+// (2) a pyramid of maxima over 2x2x2 blocks, (3) one thread per target cell descends the pyramid - nearest child
+// first, a node pruned when even its nearest cell is out of its widest claim's reach - and stops at the first source
+// cell that reaches it.  Same bytes (test_need_map_kernel_matches_tensor_form); 43 ms -> 0.7 ms on that case, and next
+// to nothing when no claim is wide (every top node is empty).
+#define NM_RWIDE 6
+#define NM_MAXLEV 12
+struct NeedPyr { int nlev; int G[NM_MAXLEV]; long long off[NM_MAXLEV]; };      // level l: G[l]^3 u64 at off[l]; level 0 = cells
+__global__ __launch_bounds__(256) void nm_up_kernel(int Gc, int Gp, const u64* child, u64* parent) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Gp * Gp * Gp) return;
+    const int px = t % Gp, py = (t / Gp) % Gp, pz = t / (Gp * Gp);
+    u64 m = 0;
+    for (int dz = 0; dz < 2; ++dz)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = 2 * px + dx, y = 2 * py + dy, z = 2 * pz + dz;
+                if (x < Gc && y < Gc && z < Gc) {
+                    const u64 v = child[((size_t)z * Gc + y) * Gc + x];
+                    m = v > m ? v : m;
+                }
+            }
+    parent[t] = m;
+}
+__global__ __launch_bounds__(256) void nm_target_kernel(NeedPyr p, const u64* pyr, double cs, unsigned char* out) {
+    const int G = p.G[0];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * G * G) return;
+    const int cx = t % G, cy = (t / G) % G, cz = t / (G * G);
+    // depth-first, explicit stack of (level, node) codes; children visited nearest first
+    unsigned stack[64 + 8 * NM_MAXLEV];            // the top level's nodes (at most 4^3) + seven more per level of descent
+    int sp = 0;
+    const int top = p.nlev - 1, Gt = p.G[top];
+    for (int q = Gt * Gt * Gt - 1; q >= 0; --q) stack[sp++] = ((unsigned)top << 27) | (unsigned)q;      // (Gt <= 4: at most 64)
+    bool hit = false;
+    while (sp > 0 && !hit) {
+        const unsigned code = stack[--sp];
+        const int lev = (int)(code >> 27);
+        const int Gl = p.G[lev];
+        const int q = (int)(code & 0x7FFFFFFu);
+        const int bx = q % Gl, by = (q / Gl) % Gl, bz = q / (Gl * Gl);
+        const u64 wb = pyr[p.off[lev] + q];
+        if (wb == 0) continue;                                       // nobody claims from here
+        // the node's cells: [b << lev, min(((b + 1) << lev) - 1, G - 1)] per axis; per-axis distance to the nearest of them
+        const int x0 = bx << lev, y0 = by << lev, z0 = bz << lev;
+        const int x1 = min(((bx + 1) << lev) - 1, G - 1), y1 = min(((by + 1) << lev) - 1, G - 1), z1 = min(((bz + 1) << lev) - 1, G - 1);
+        const int dx = max(max(x0 - cx, cx - x1), 0), dy = max(max(y0 - cy, cy - y1), 0), dz = max(max(z0 - cz, cz - z1), 0);
+        const int ax = max(dx - 1, 0), ay = max(dy - 1, 0), az = max(dz - 1, 0);
+        const double qv = __longlong_as_double((long long)wb) / cs;
+        if (!((double)(ax * ax + ay * ay + az * az) <= qv * qv)) continue;          // out of the widest claim's reach
+        if (lev == 0) { hit = true; break; }
+        // children: the one nearest to the target last on the stack (= first off it)
+        const int lc = lev - 1, Gc = p.G[lc];
+        const int px = (cx >> lc) > 2 * bx ? 1 : 0, py = (cy >> lc) > 2 * by ? 1 : 0, pz = (cz >> lc) > 2 * bz ? 1 : 0;
+        const int pref = px | (py << 1) | (pz << 2);
+        for (int k = 7; k >= 0; --k) {
+            const int c = k ^ pref;
+            const int x = 2 * bx + (c & 1), y = 2 * by + ((c >> 1) & 1), z = 2 * bz + (c >> 2);
+            if (x < Gc && y < Gc && z < Gc) stack[sp++] = ((unsigned)lc << 27) | (unsigned)((z * Gc + y) * Gc + x);
+        }
+    }
+    if (hit) out[t] = 1;                               // (beside the narrow claims' marks)
+}
+
 extern "C" int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, const double* w, const double* g_lo,
                                  double g_cs, int G, unsigned char* out) {
     if (!ctx) return SPHX_E_ARG;
     NEED(g_lo); NEED(out);
-    if (n < 0 || G < 1 || G > 1024 || !(g_cs > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "need map: n=%lld G=%d cs=%g", (long long)n, G, g_cs);
+    if (n < 0 || G < 1 || G > 512 || !(g_cs > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "need map: n=%lld G=%d (1..512) cs=%g", (long long)n, G, g_cs);
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemsetAsync(out, 0, (size_t)G * G * G, ctx->stream));
-    if (n == 0) return SPHX_OK;
+    if (n == 0) {
+        HIPCHK(hipMemsetAsync(out, 0, (size_t)G * G * G, ctx->stream));
+        return SPHX_OK;
+    }
     NEED(pos); NEED(w);
+    NeedPyr p;
+    p.nlev = 0;
+    long long tot = 0;
+    for (int g = G;; g = (g + 1) / 2) {
+        p.G[p.nlev] = g; p.off[p.nlev] = tot;
+        tot += (long long)g * g * g;
+        ++p.nlev;
+        if (g <= 4 || p.nlev == NM_MAXLEV) break;
+    }
+    if (p.G[p.nlev - 1] > 4) return sphx_set_err(ctx, SPHX_E_ARG, "need map: G=%d too large for the pyramid", G);
+    SPHX_TRY(sphx_ensure(ctx, ctx->need_pyr, (size_t)tot * sizeof(u64)));
+    u64* pyr = ctx->need_pyr.as<u64>();
+    HIPCHK(hipMemsetAsync(pyr, 0, (size_t)G * G * G * sizeof(u64), ctx->stream));        // (level 0; the others are overwritten)
+    HIPCHK(hipMemsetAsync(out, 0, (size_t)G * G * G, ctx->stream));
     hipLaunchKernelGGL(need_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, pos, w,
-                       g_lo[0], g_lo[1], g_lo[2], g_cs, G, out);
+                       g_lo[0], g_lo[1], g_lo[2], g_cs, G, out, NM_RWIDE, pyr);
+    for (int l = 1; l < p.nlev; ++l) {
+        const int gp = p.G[l];
+        hipLaunchKernelGGL(nm_up_kernel, dim3((unsigned)((gp * gp * gp + 255) / 256)), dim3(256), 0, ctx->stream, p.G[l - 1], gp,
+                           pyr + p.off[l - 1], pyr + p.off[l]);
+    }
+    hipLaunchKernelGGL(nm_target_kernel, dim3((unsigned)((G * G * G + 255) / 256)), dim3(256), 0, ctx->stream, p, pyr, g_cs, out);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
