@@ -309,6 +309,8 @@ def test_need_map_kernel_matches_tensor_form():
     w = torch.rand(n, generator=g, dtype=torch.float64) * 0.03
     w[::97] = 0.0                        # claims nothing
     w[5::211] = 0.2                      # several cells
+    w[11::97] = 0.45                     # ~11 cells: marked from the target side (the pyramid of per-cell maxima)
+    w[13::389] = 0.8                     # ~19 cells
     w[7] = 1.0 / 24                      # exactly one cell edge
     w[3] = 50.0                          # the whole grid
 
@@ -324,11 +326,11 @@ def test_need_map_kernel_matches_tensor_form():
         s_.s = dict(pos=pos_.to(dev))
         return s_._need_map(w_.to(dev))
 
-    for sl in (slice(None), slice(8, None), slice(0, 3), slice(0, 0)):
+    for sl in (slice(None), slice(8, None), slice(0, 3), slice(0, 0), slice(8, 400), slice(11, 12)):
         a, b = sim(Plain(), pos[sl], w[sl]), sim(be, pos[sl], w[sl])
         assert a.dtype == b.dtype == torch.uint8 and a.shape == b.shape
         assert torch.equal(a, b), int((a != b).sum())
-    assert 0 < int(sim(be, pos[8:], w[8:]).sum()) < G ** 3      # a non-trivial map
+    assert 0 < int(sim(be, pos[8:400], w[8:400]).sum()) < G ** 3      # a non-trivial map
     torch.cuda.synchronize()
 
 
