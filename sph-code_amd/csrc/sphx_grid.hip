@@ -683,7 +683,12 @@ int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
     SPHX_TRY(sphx_ensure(ctx, ctx->mstart, ((size_t)M + 2) * sizeof(int)));
     int* mc = ctx->mcount.as<int>();
     int* ms = ctx->mstart.as<int>();
-    HIPCHK(hipMemsetAsync(mc, 0, ((size_t)M + 1) * sizeof(int), ctx->stream));
+    // (all zero between builds when the deferred scatter below cleans up after the scan: no memset then, except once per
+    //  allocation or after a build that did not)
+    if (!(ctx->mcount_zeroed == ctx->mcount.p && ctx->mcount_zeroed_M == M)) {
+        HIPCHK(hipMemsetAsync(mc, 0, ctx->mcount.cap, ctx->stream));
+    }
+    ctx->mcount_zeroed = nullptr;
     hipLaunchKernelGGL(blob_count, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, ctx->stream, g, b,
                        ctx->cell_start.as<int>(), mc, ctx->cells_unsorted ? ctx->perm.as<int>() : nullptr);
     ctx->cells_unsorted = false;
@@ -694,6 +699,8 @@ int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
         ctx->blob_scatter_pending = true;
         ctx->blob_scatter_bits = b;
         ctx->blob_scatter_mstart = ms;
+        ctx->mcount_zeroed = ctx->mcount.p;        // (the scatter puts the counts it used back to zero)
+        ctx->mcount_zeroed_M = M;
     } else {
         hipLaunchKernelGGL(blob_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, g, b,
                            ctx->cell_of.as<int>(), ctx->perm.as<int>(), ctx->cell_start.as<int>(), ms,

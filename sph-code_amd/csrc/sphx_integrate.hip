@@ -43,6 +43,7 @@ struct GatherArgs {
     GridParams bs_g; BlobBits bs_b;
     const int *bs_cell_of, *bs_cell_start, *bs_mstart;
     int* bs_porder;
+    int* bs_mcount;                    // the curve's per-cell counts: put back to zero here (the scan has read them)
 };
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,7 +52,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     if (a.bs_porder) {
         const int c = a.bs_cell_of[p];
         const int cx = c % a.bs_g.nx, cy = (c / a.bs_g.nx) % a.bs_g.ny, cz = c / (a.bs_g.nx * a.bs_g.ny);
-        a.bs_porder[a.bs_mstart[blob_rank(cx, cy, cz, a.bs_b)] + (t - a.bs_cell_start[c])] = t;
+        const unsigned rk = blob_rank(cx, cy, cz, a.bs_b);
+        a.bs_porder[a.bs_mstart[rk] + (t - a.bs_cell_start[c])] = t;
+        if (t == a.bs_cell_start[c]) a.bs_mcount[rk] = 0;          // (one member per cell cleans up)
     }
     for (int q = 0; q < a.narr; ++q) a.dst[q][t] = a.src[q][p];
     if (a.id_src) {
@@ -84,6 +87,7 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split, hipEvent_t after_fi
         g.bs_g = ctx->grid; g.bs_b = ctx->blob_scatter_bits;
         g.bs_cell_of = ctx->cell_of.as<int>(); g.bs_cell_start = ctx->cell_start.as<int>();
         g.bs_mstart = ctx->blob_scatter_mstart; g.bs_porder = ctx->porder.as<int>();
+        g.bs_mcount = ctx->mcount.as<int>();
         ctx->blob_scatter_pending = false;
     }
     g.n = (int)n; g.narr = 16; g.s = ctx->sp;

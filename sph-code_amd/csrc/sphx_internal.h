@@ -198,6 +198,8 @@ struct sphx_ctx {
     bool bbox_ticket_zeroed = false;
     bool defer_cell_sort = false, cells_unsorted = false;   // the per-cell member sort rides in the blob-order pass
     bool defer_blob_scatter = false, blob_scatter_pending = false;   // the blob order's last scatter rides in the state's permutation
+    const void* mcount_zeroed = nullptr;   // the blob-count allocation known to be all zero (cleaned by the deferred scatter)
+    int mcount_zeroed_M = 0;
     BlobBits blob_scatter_bits;
     const int* blob_scatter_mstart = nullptr;
     bool species_lds = true;        // SPHX_SPECIES_LDS=0: the species pass by gathers (sphx_sums.hip) also when blob lists exist
