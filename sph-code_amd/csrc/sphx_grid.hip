@@ -321,15 +321,36 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int n, const int* in, 
     }
 }
 
+// bb_part != nullptr (the fused loop): the first BB_W blocks also fold one column each of the box statistics' block
+// partials (what bbox_final does: same order of operations) - they are wanted by the search and by the next step's host code,
+// not by anything before this kernel, so they need no launch of their own on the way (early blocks: off the kernel's tail).
 __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, const int* cell_start,
-                                                    int* fill, int* perm) {
+                                                    int* fill, int* perm, int bb_nblocks, const double* bb_part,
+                                                    double* bb_out) {
+    __shared__ double sw[4];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = cell_of[i];
-    // counts the histogram back down to zero; slots are handed out upwards (arrival order is mostly
-    // the previous cell order already, which the per-cell insertion sort then finds nearly sorted)
-    int slot = cell_start[c + 1] - atomicSub(&fill[c], 1);
-    perm[slot] = i;
+    if (i < n) {
+        int c = cell_of[i];
+        // counts the histogram back down to zero; slots are handed out upwards (arrival order is mostly
+        // the previous cell order already, which the per-cell insertion sort then finds nearly sorted)
+        int slot = cell_start[c + 1] - atomicSub(&fill[c], 1);
+        perm[slot] = i;
+    }
+    if (bb_part && (int)blockIdx.x < BB_W && (int)gridDim.x >= BB_W) {
+        const int c = blockIdx.x;
+        double v = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.0);
+        for (int b = threadIdx.x; b < bb_nblocks; b += 256) {
+            const double p = bb_part[b * BB_W + c];
+            v = c < 3 ? fmin(v, p) : (c < 6 ? fmax(v, p) : v + p);
+        }
+        v = c < 3 ? wave_min(v) : (c < 6 ? wave_max(v) : wave_sum(v));
+        if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double a0 = sw[0], a1 = sw[1], a2 = sw[2], a3 = sw[3];
+            bb_out[c] = c < 3 ? fmin(fmin(a0, a1), fmin(a2, a3)) : (c < 6 ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3));
+        }
+    }
 }
 
 // The atomic scatter fills a cell in arrival order; sorting each cell's slice by the particles'
@@ -473,6 +494,9 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     }
     int pb = (int)((n + 255) / 256);
     (void)bsum;
+    int bb_fold_blocks = 0;
+    const double* bb_fold_part = nullptr;
+    double* bb_fold_out = nullptr;
     if (fused) {
         // clamp (when the step asked for it) + this step's box statistics + cell ids + histogram: one pass
         const bool fresh = ctx->bbox_tmp.p == nullptr;
@@ -504,16 +528,13 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         ctx->ct_primed = true;
         int fb = pb < FUSED_MAXBLOCKS ? pb : FUSED_MAXBLOCKS;
         hipLaunchKernelGGL(grid_count_fused, dim3(fb), dim3(RED_BLOCK), 0, ctx->stream, fa);
-        hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(256), 0, ctx->stream, fb, part, fin);
         HIPCHK(hipGetLastError());
         ctx->clamp_vx = nullptr;
-        char* slot = (char*)ctx->pinned + LAG_OFF;
-        HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, fin, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->step_ev1) {
-            ctx->lag_balias[lag_cur] = ctx->step_ev1;          // recorded by the caller a few launches on, before the search
+        if (pb >= BB_W) {
+            bb_fold_blocks = fb; bb_fold_part = part; bb_fold_out = fin;   // folded by cell_scatter's first blocks, copied out there
         } else {
-            HIPCHK(hipEventRecord(ctx->lag_bev[lag_cur], ctx->stream));
-            ctx->lag_balias[lag_cur] = nullptr;
+            hipLaunchKernelGGL(bbox_final, dim3(BB_W), dim3(256), 0, ctx->stream, fb, part, fin);
+            bb_fold_out = fin;                                             // (a handful of particles: its own launch, copied out below)
         }
     } else {
         hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
@@ -521,7 +542,17 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     }
     SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc));
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>());
+                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out);
+    if (bb_fold_out) {
+        char* slot = (char*)ctx->pinned + LAG_OFF;
+        HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, bb_fold_out, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->step_ev1) {
+            ctx->lag_balias[lag_cur] = ctx->step_ev1;          // recorded by the caller a few launches on, before the search
+        } else {
+            HIPCHK(hipEventRecord(ctx->lag_bev[lag_cur], ctx->stream));
+            ctx->lag_balias[lag_cur] = nullptr;
+        }
+    }
     ctx->cells_unsorted = false;
     if (ctx->defer_cell_sort) {
         ctx->cells_unsorted = true;          // sphx_build_blob_order's per-cell pass sorts the members too
