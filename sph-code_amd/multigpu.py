@@ -1237,7 +1237,9 @@ def bench_main(args, rank, local_rank, world):
                             "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
             "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "search (rank 0): knn_group_kernel + knn_kernel<0,2,1> (list mode)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,
                                         "peak": 8000.0, "unit": "GB/s", "frac": 192.0 * q / (ms * 1e-3) / 1e9 / 8000.0,
-                                        "traffic": None, "algorithmic_bytes_per_launch": 192.0 * q,
+                                        "traffic": None,
+                                        "traffic_source": "not collected for N > 1: the PMC passes run on the single-GPU bench (profiles/r02_final_pmc_per_launch.json)",
+                                        "algorithmic_bytes_per_launch": 192.0 * q,
                                         "kernel_ms": ms, "queries_per_launch": q})(
                 kst["ms_search"] / max(kst["steps"], 1), sim.n_owned) if kst["steps"] else None,
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
