@@ -712,8 +712,7 @@ int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double
     int agb_on = (ctx->agb_on && Z && agb) ? 1 : 0;
     if (getenv("SPHX_EXP_NO_AGB")) agb_on = 0;          // timing experiment: the species sums alone
     // out of LDS when the step's blob lists are at hand (sphx_blob.hip); the gather form below otherwise
-    if (ctx->use_lds && ctx->blob_lists && ctx->qorder && !ctx->map_perm && SP == 16 && S <= 16 && k <= SPHX_MAX_K &&
-        ctx->species_lds)
+    if (ctx->use_lds && ctx->blob_lists && ctx->qorder && SP == 16 && S <= 16 && k <= SPHX_MAX_K && ctx->species_lds)
         return sphx_blob_species(ctx, n, k, S, fun_sorted, m_sorted, F, Z, agb, agb_on);
     if (S <= 16)       // the reference's 15 species: sums in 16 registers
         hipLaunchKernelGGL(step_species_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
