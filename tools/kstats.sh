@@ -7,7 +7,7 @@ OUT="$ROOT/gpurun_out/ks_$PREFIX"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ks -- \
-    python3 "$ROOT/bench.py" --no-cpu --steps 20 --warmup 3 "$@" > "$OUT/run.log" 2>&1
+    python3 "$ROOT/bench.py" --no-cpu --device-warmup 0 --steps 20 --warmup 3 "$@" > "$OUT/run.log" 2>&1
 grep '^{' "$OUT/run.log" | tail -1 > "$ROOT/gpurun_out/${PREFIX}_bench.json"
 f=$(find "$OUT" -name '*kernel_stats.csv' | head -1)
 cp "$f" "$ROOT/gpurun_out/${PREFIX}_kernel_stats.csv"

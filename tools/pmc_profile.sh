@@ -21,7 +21,7 @@ GROUPS_=(
 g=0
 for grp in "${GROUPS_[@]}"; do
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace ${KREGEX:+--kernel-include-regex "$KREGEX"} --output-format csv -d "$OUT/g$g" -o pmc -- \
-      python3 "$ROOT/bench.py" --no-cpu --steps 3 --warmup 1 "$@" > "$OUT/g$g.log" 2>&1 || echo "group $g failed (see $OUT/g$g.log)"
+      python3 "$ROOT/bench.py" --no-cpu --device-warmup 0 --steps 3 --warmup 1 "$@" > "$OUT/g$g.log" 2>&1 || echo "group $g failed (see $OUT/g$g.log)"
   g=$((g+1))
 done
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" > "$ROOT/gpurun_out/${PREFIX}_pmc_per_launch.json"
