@@ -356,18 +356,57 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
 // The atomic scatter fills a cell in arrival order; sorting each cell's slice by the particles'
 // previous index makes the cell-sorted order (and everything derived from it: tie-breaks in the
 // search, summation order) identical from run to run.  Cells hold a few particles each.
+// A cell's members into ascending order, one lane per cell - for the few particles a cell normally holds.  A diverging
+// run piles hundreds of escapers into single boundary cells (the corners of the drv:233 clamp cube: identical positions);
+// one lane's insertion sort then costs cnt^2 steps and the grid build grew from 0.2 to 4.5 ms over 300 steps of such a run.
+// Cells of 17 .. 512 members are therefore sorted by the whole WAVE: every lane holds up to eight members, finds each
+// one's rank by comparing it with all of them (broadcast lane by lane: members are distinct indices) and writes it to
+// its place - all reads before any write.  Beyond 512 the arrival order stays (a valid cell list; only run-to-run
+// tie-breaking is lost).  Every lane of the wave must call this (cnt = 0: nothing to do).
+#define CELL_SORT_SERIAL 16
+#define CELL_SORT_WAVE 512
+__device__ __forceinline__ void sort_cell_members(int* perm, int s, int cnt, bool on) {
+    if (on && cnt > 1 && cnt <= CELL_SORT_SERIAL) {
+        for (int i = s + 1; i < s + cnt; ++i) {
+            const int v = perm[i];
+            int j = i - 1;
+            while (j >= s && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
+            perm[j + 1] = v;
+        }
+    }
+    u64 big = __builtin_amdgcn_ballot_w64(on && cnt > CELL_SORT_SERIAL && cnt <= CELL_SORT_WAVE);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+        const int t = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bs = __builtin_amdgcn_readlane(s, t), m = __builtin_amdgcn_readlane(cnt, t);
+        constexpr int U = CELL_SORT_WAVE / 64;
+        int v[U], rank[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = lane + 64 * u;
+            v[u] = q < m ? perm[bs + q] : 0x7FFFFFFF;
+            rank[u] = 0;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < U; ++c2) {
+            const int lc = m - 64 * c2 < 64 ? m - 64 * c2 : 64;
+            for (int tt = 0; tt < lc; ++tt) {
+                const int kt = __builtin_amdgcn_readlane(v[c2], tt);
+#pragma unroll
+                for (int u = 0; u < U; ++u) rank[u] += kt < v[u] ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lane + 64 * u < m) perm[bs + rank[u]] = v[u];
+    }
+}
 __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* cell_start, int* perm) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncells) return;
-    const int s = cell_start[c], e = cell_start[c + 1];
-    if (e - s > 512) return;      // pathologically crowded cell: leave arrival order (still a valid
-                                  // cell list; only run-to-run tie-breaking is lost) rather than O(n^2)
-    for (int i = s + 1; i < e; ++i) {
-        const int v = perm[i];
-        int j = i - 1;
-        while (j >= s && perm[j] > v) { perm[j + 1] = perm[j]; --j; }
-        perm[j + 1] = v;
-    }
+    int s = 0, cnt = 0;
+    if (c < ncells) { s = cell_start[c]; cnt = cell_start[c + 1] - s; }
+    sort_cell_members(perm, s, cnt, true);
 }
 
 #define SPHX_MAX_CELLS (SCAN_TILE * 4096)
@@ -659,18 +698,10 @@ int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const 
 __global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount,
                                                   int* sort_perm) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.ncells) return;
-    const int s0 = cell_start[c], e0 = cell_start[c + 1];
-    const int cnt = e0 - s0;
+    int s0 = 0, cnt = 0;
+    if (c < g.ncells) { s0 = cell_start[c]; cnt = cell_start[c + 1] - s0; }
+    sort_cell_members(sort_perm, s0, cnt, sort_perm != nullptr);       // (the whole wave: crowded cells are sorted together)
     if (cnt == 0) return;
-    if (sort_perm && cnt <= 512) {
-        for (int i = s0 + 1; i < e0; ++i) {
-            const int v = sort_perm[i];
-            int j = i - 1;
-            while (j >= s0 && sort_perm[j] > v) { sort_perm[j + 1] = sort_perm[j]; --j; }
-            sort_perm[j + 1] = v;
-        }
-    }
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     mcount[blob_rank(cx, cy, cz, b)] = cnt;
 }

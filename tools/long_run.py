@@ -12,6 +12,8 @@ n = 1000000
 s0 = ics.WORKLOADS[wl](n, light=True)
 kw = dict(forms="loop", d=ics.loop_d(s0, 40)) if forms == "loop" else {}
 sim = Simulation(s0, n_neigh=40, **kw)
+if os.environ.get("LONG_RUN_DETAIL"):
+    sim.ctx.set_timing_detail(True)
 sim.step(3)
 done = 3
 while done < total:
@@ -26,3 +28,7 @@ while done < total:
     print("steps %4d-%4d  %.3f ms/step  search %.3f  cells %8d  fallback %6d far %6d levels %2d  h mean %.3g max %.3g  max|v| %.3g" % (
         done - 50, done, dt / 50 * 1e3, st["ms_search"] / max(st["steps"], 1), st["cells"], st["fallback_queries"], st["far_queries"],
         st["outlier_levels"], h.mean(), h.max(), np.abs(d["velocities"]).max()), flush=True)
+    if st["detail_steps"]:
+        ds = float(st["detail_steps"])
+        print("        per pass: " + "  ".join("%s %.3f" % (k_[3:], st[k_] / ds) for k_ in
+              ("ms_grid", "ms_prep", "ms_density", "ms_pi", "ms_visc", "ms_integrate")), flush=True)
