@@ -194,15 +194,26 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
     // list mode: 4 queries per wave and pass instead of 16 - the list is short (a few per cent of the queries), so
     // the launch is bound by how long one wave takes, not by how many waves there are
     constexpr int PPB = LIST ? KNN_LIST_PPB : KNN_PPB;
-    if (LIST && vblock * PPB >= total) break;
     const int base = vblock * PPB;
+    // Which query is the workgroup's li-th (li = 4 wave + its turn)?  Normally the li-th of its block of consecutive ones.
+    // In list mode the list is dealt out wave by wave instead - entry r NW + w goes to wave w of all NW as its r-th -
+    // because the list's heavy entries come in runs (the 64 queries of an overflowed group, a pile of escapers in one
+    // boundary cell): consecutive entries must not queue up behind each other in one wave.
+    const int list_pass = LIST ? (vblock - (int)blockIdx.x) / (int)gridDim.x : 0;
+    const int NWV = (int)gridDim.x * (KNN_BLOCK / 64);
+    auto entry_of = [&](int li) -> int {
+        if (!LIST) return base + li;
+        const int wv = li / (PPB / 4), turn = li % (PPB / 4);
+        return (list_pass * (PPB / 4) + turn) * NWV + (int)blockIdx.x * (KNN_BLOCK / 64) + wv;
+    };
+    if (LIST && entry_of(0) >= total) break;       // (the workgroup's smallest entry of this pass and of all later ones)
     // the wave's 16 query particles are fetched in ONE coalesced round trip (lane l holds
     // particle l) and broadcast through SGPRs as each comes up
     double qx = 0.0, qy = 0.0, qz = 0.0, qr = 0.0;
     int qid = 0x7FFFFFFF;
     int qs = 0;                      // where the lane's query particle is stored
     {
-        const int ip = base + wave * (PPB / 4) + (lane & 15);
+        const int ip = entry_of(wave * (PPB / 4) + (lane & 15));
         if (lane < PPB / 4 && ip < total) {
             // (a list entry: processing slot in the low 29 bits; in the top three, how much wider than the hint to start -
             //  the grouped kernel counted fewer than K inside it: 1 .. 7 = x1.6 .. x3, sphx_knn_group.hip)
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
         const int li = wave * (PPB / 4) + t16;
         const int oid = __builtin_amdgcn_readlane(qid, t16);
         // wave-uniform: past the end, or a ghost (a candidate, never a query)
-        if (base + li >= total || oid >= a.n_active) {
+        if (entry_of(li) >= total || oid >= a.n_active) {
             if (lane < K) tile(lane, li) = -1;
             continue;
         }
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
     if (LEAN || a.nbr) {
         __syncthreads();
         if (LIST) {
-            const int i = base + lane;
+            const int i = entry_of(lane < PPB ? lane : 0);
             const int slot = (lane < PPB && i < total) ? (int)((unsigned)a.qlist[i] & 0x1FFFFFFFu) : -1;
             for (int kk = wave; kk < K; kk += KNN_BLOCK / 64)
                 if (slot >= 0) a.nbr[(long long)kk * a.npad + slot] = tile(kk, lane);
