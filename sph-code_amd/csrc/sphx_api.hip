@@ -85,6 +85,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
     if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
     if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
@@ -521,7 +522,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
             if (hmean > 0.0 && isfinite(hmean)) {
                 cell_hint = ctx->cell_factor * hmean;
-                ctx->h_clip = 8.0 * hmean;
+                ctx->h_clip = ctx->h_clip_factor * hmean;
             }
         }
         {

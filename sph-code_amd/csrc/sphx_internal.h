@@ -249,6 +249,7 @@ struct sphx_ctx {
     bool clip_valid = false;
     double box_sigmas = 3.0;        // the grid covers mean +- this many standard deviations of the positions (SPHX_BOX_SIGMAS)
     double h_clip = 0.0;            // h above this is left out of the mean that sizes the cells (0: none)
+    double h_clip_factor = 8.0;     // ... = this many times the previous mean (SPHX_HCLIP)
     DevBuf cell_of, cell_start, cell_fill, perm, inv, scan_tmp, bbox_tmp;
     // ---- host-API staging ----
     DevBuf in_a, in_b, in_c, in_d, in_e, in_f, in_g, in_h, in_i, in_j, out_a, out_b, out_c;
