@@ -476,6 +476,9 @@ class DistributedSim:
         # than the skin), the next steps replan without asking - two host-synchronising reductions less
         self.stale_streak, self.force_replan = 0, 0
         self._nonzero_static = None       # torch.nonzero_static usable on this device? (found out at the first plan)
+        # how much of |v_i| dt a particle adds to the reach it claims (1: a radius may grow by the particle's own displacement
+        # per step; every plan is verified after the search and redone if too thin, so this only trades ghosts for redos)
+        self.reach_vfac = float(os.environ.get("SPHX_REACH_VFAC", "1.0"))
         self.plan_next = None             # the NEXT step's plan, made at the end of this one (see step)
         self.plan_ahead = True
         # coarse global grid for the need maps: global bounding box of the initial state + 25 %
@@ -720,11 +723,11 @@ class DistributedSim:
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
         # (a radius changes by at most twice the local displacement, so fast movers claim more)
         if hasattr(self.backend, "reach") and self.n_owned:
-            self.w_plan = self.backend.reach(s["h"], s["vel"], self.halo_scale, self.skin_frac, self.dt_last)
+            self.w_plan = self.backend.reach(s["h"], s["vel"], self.halo_scale, self.skin_frac, self.dt_last * self.reach_vfac)
         else:
             speed = torch.sqrt((s["vel"] * s["vel"]).sum(dim=1))
             self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"],
-                                        self.halo_scale * s["h"] + speed * self.dt_last)
+                                        self.halo_scale * s["h"] + speed * (self.dt_last * self.reach_vfac))
         if self.world > 1:
             self.send_idx, self.recv_counts = self._plan(self.w_plan)
         else:
@@ -939,7 +942,8 @@ class DistributedSim:
                 if ahead_ok:
                     with self._sec("plan_ahead"):
                         be.clamp(s["pos"], s["vel"])            # drv:233-238, early: the next step's own clamp finds nothing to do
-                        w_next = be.reach_dt(h[:no].contiguous(), s["vel"], self.halo_scale, self.skin_frac, dt_t)
+                        w_next = be.reach_dt(h[:no].contiguous(), s["vel"], self.halo_scale, self.skin_frac,
+                                             dt_t if self.reach_vfac == 1.0 else dt_t * self.reach_vfac)
                         mask_next, both_next = self._plan_launch(w_next)
                         ahead = (w_next, mask_next)
                 if ahead is not None and both_next.device == red_dev.device:
@@ -957,6 +961,8 @@ class DistributedSim:
             if no:
                 fail = h[:no] + 2.0 * D > self.w_plan
                 s["h"] = torch.where(fail, 1.5 * (h[:no] + 2.0 * D), s["h"])
+            # (a migration inside the redo sorts by THIS attempt's search: the state has not moved since)
+            self.last_ntotal = int(pos.shape[0])
             with self._sec("replan"):
                 self._replan()
             D = 0.0

@@ -115,6 +115,9 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update
     if os.environ.get("SPHX_TEST_FORCE_REPLAN"):      # the regime of the reference's dt rule: a new plan every step
         sim.force_replan = int(os.environ["SPHX_TEST_FORCE_REPLAN"])
         sim.plan_ahead = os.environ.get("SPHX_TEST_PLAN_AHEAD", "1") != "0"
+    if os.environ.get("SPHX_TEST_THIN_PLANS"):        # no head-room at all: any radius that grows makes the step redo
+        sim.halo_scale, sim.skin_frac, sim.reach_vfac = 1.0, 0.0, 0.0
+        sim.migrate_every = 3                         # (with a redo per step: migrations fall on redos too)
     n_ahead = 0
     for _ in range(nsteps):
         sim.step()
@@ -153,6 +156,28 @@ def test_ranks_sharing_one_gpu_match_oracle(world, workload, tmp_path):
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
     np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-9)
     assert sum(p["stats"][0] for p in parts) > 0
+
+
+def test_two_ranks_redone_steps_match_oracle(tmp_path, monkeypatch):
+    """Plans with no head-room (claimed reach = the previous radius itself, no skin, no velocity term): the post-search verdict finds them too thin, the failing
+    particles claim more, everybody replans - migrating by the order of the attempt just made when a migration is due -
+    and the step's search and sums are redone.  Same trajectories as the oracle's single-domain step."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    n, nsteps, world = 12000, 4, 2
+    monkeypatch.setenv("SPHX_TEST_THIN_PLANS", "1")
+    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, "polytrope", str(tmp_path)), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    assert min(int(p["stats"][1]) for p in parts) >= 2                   # redone steps (the same count on every rank)
+    order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+    got = {k_: np.concatenate([p[k_] for p in parts])[order] for k_ in ("points", "velocities", "sizes", "densities")}
+    ref = ics.WORKLOADS["polytrope"](n, light=True)
+    for it in range(nsteps):
+        ref = orc.step(ref, n_neigh=K, eps=0.0, first=(it == 0))
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-11)
+    assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * np.max(np.abs(ref["points"]))
+    assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
 
 
 @pytest.mark.parametrize("forms", ["hydro_update", "loop"])
