@@ -366,6 +366,15 @@ int sphx_dev_loop_pass1(sphx_ctx* ctx, const double* h_complete, double* rho, do
 /* nsc.artificial_viscosity + crossing_time (nsc:776-816); rho_complete (n_total): ghosts' from their owners (nsc:803).
  * ct_out as sphx_dev_pi.                                                                                                */
 int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_accel, double* visc_heat, double* ct_out);
+/* Overlap of pass 2 with the rho_j halo phase.  The search sorts its workgroups of 128 particles ("blobs") by what they
+ * need from other ranks: interior (every neighbour of its owned particles is owned), boundary, idle (ghosts only).
+ * sphx_dev_loop_pass2_interior, called after sphx_dev_loop_pass1 and BEFORE the ghosts' densities have arrived, launches
+ * pass 2 for the interior blobs (they read only densities pass 1 left on the device); the sphx_dev_loop_pass2 that
+ * follows then runs the boundary blobs and delivers the outputs.  Returns 1 if launched, 0 if there is nothing to
+ * split (LDS passes off: sphx_dev_loop_pass2 does everything), < 0 on error.  Results do not depend on the split.
+ * sphx_dev_blob_split_counts: {interior, boundary, idle} blobs of the last search (a device-to-host read: diagnostics). */
+int sphx_dev_loop_pass2_interior(sphx_ctx* ctx);
+int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]);
 /* drv:460-491 on those outputs: pressure_accel = delp / rho [gas], visc_accel = av[0].  red2 == NULL: the step `dt`;
  * else verdict and dt on the device as sphx_dev_integrate_auto (dt_out required).                                       */
 int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* pos, double* vel, double* accel_old,

@@ -88,6 +88,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
     if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
     if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
@@ -472,6 +473,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
+    ctx->blob_split_valid = false;
     ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
     if (rec0) HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238: applied by the grid build's first pass over the particles (sphx_grid.hip); the Verlet path looks at

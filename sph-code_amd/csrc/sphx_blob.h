@@ -143,4 +143,15 @@ __device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
 }
 
 
+// The blobs a launch works through: all nblk of them, or one of blob_split_kernel's lists (decomposed runs: the
+// interior blobs while a halo phase is in flight, the boundary blobs after it) - its length read from device memory.
+struct BlobSel { const int* list; const int* cnt; };
+__device__ __forceinline__ int blob_sel_count(const BlobSel& s, int nblk) { return s.list ? *s.cnt : nblk; }
+__device__ __forceinline__ int blob_sel_at(const BlobSel& s, int bi, int count) {
+    const int q = xcd_block(bi, count);
+    return s.list ? s.list[q] : q;
+}
+// part: 0 all blobs, 1 the interior ones, 2 the boundary ones (needs ctx->blob_split_valid)
+BlobSel sphx_blob_sel(sphx_ctx* ctx, int part);
+
 int sphx_blob_grid(sphx_ctx* ctx, int nblk);       // persistent grid of the LDS passes (2 workgroups per CU)

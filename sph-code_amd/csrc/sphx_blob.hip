@@ -40,9 +40,14 @@
 #define DD_PROBES 64
 __device__ __forceinline__ unsigned dd_hash(int j) { return ((unsigned)j * 2654435761u) >> 21; }
 
+// bclass (device API, decomposed runs; nullptr otherwise): what the workgroup's particles need from other ranks -
+// 0 "interior": some of its particles are owned and every neighbour of theirs is owned too, so its sums can run before
+// the ghosts' values of the step have arrived; 1 "boundary"; 2: all of its particles are ghosts (nothing to compute).
 __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int k, int slots,
                                                             const int* __restrict__ nbr, u16* slot16,
-                                                            int* uniq) {
+                                                            int* uniq, const int* __restrict__ qorder,
+                                                            const int* __restrict__ omap, int n_active,
+                                                            unsigned char* bclass) {
     extern __shared__ u16 dd_tile[];              // [k][BLOB_P] entry / slot numbers
     __shared__ int key[DD_TAB];
     __shared__ u16 slot_of[DD_TAB];
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
         total += tw;
     }
     int* uq = uniq + (size_t)b * BLOB_S;
+    int needs_ghost = 0;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int j = key[e0 + q];
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
             slot_of[e0 + q] = (u16)(base < slots ? base : SLOT_OVER);
             if (base < slots) uq[base] = j;
             ++base;
+            if (bclass && omap[j] >= n_active) needs_ghost = 1;
         }
     }
     for (int q = (total < slots ? total : slots) + threadIdx.x; q < BLOB_S; q += BLOB_T) uq[q] = -1;
@@ -151,11 +158,45 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
         for (int u = 0; u < 8; ++u) {
             const unsigned e = src[u];
             v[u] = e < DD_TAB ? (unsigned)slot_of[e] : e;
+            if (v[u] == SLOT_OVER) needs_ghost = 1;      // (an unstaged neighbour is not looked up here: taken as foreign)
         }
         if ((size_t)b * BLOB_P + c * 8 < (size_t)npad)
             *reinterpret_cast<uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8) =
                 make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
     }
+    if (bclass) {                                          // (uniform: a kernel argument)
+        const int owned_q = (half == 0 && p < n && omap[qorder[p]] < n_active) ? 1 : 0;
+        const int any_owned = __syncthreads_or(owned_q);
+        const int any_ghost = __syncthreads_or(needs_ghost);
+        if (threadIdx.x == 0) bclass[b] = (unsigned char)(!any_owned ? 2 : (any_ghost ? 1 : 0));
+    }
+}
+
+// interior blobs, then boundary blobs, each in blob order: list[0 .. cnt[0]) and list[nblk .. nblk + cnt[1]).
+// One workgroup (a few thousand blobs per 10^6 particles); each thread takes a run of consecutive blobs.
+#define SPLIT_T 1024
+__global__ __launch_bounds__(SPLIT_T) void blob_split_kernel(int nblk, const unsigned char* __restrict__ bclass, int* list,
+                                                             int* cnt) {
+    __shared__ int wsum[2][SPLIT_T / 64];
+    const int per = (nblk + SPLIT_T - 1) / SPLIT_T;
+    const int b0 = threadIdx.x * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    int c0 = 0, c1 = 0;
+    for (int b = b0; b < b1; ++b) { const int c = bclass[b]; c0 += c == 0; c1 += c == 1; }
+    const int i0 = wave_scan_incl(c0), i1 = wave_scan_incl(c1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 63) { wsum[0][wv] = i0; wsum[1][wv] = i1; }
+    __syncthreads();
+    int o0 = i0 - c0, o1 = i1 - c1, t0 = 0, t1 = 0;
+    for (int w = 0; w < SPLIT_T / 64; ++w) {
+        if (w < wv) { o0 += wsum[0][w]; o1 += wsum[1][w]; }
+        t0 += wsum[0][w]; t1 += wsum[1][w];
+    }
+    for (int b = b0; b < b1; ++b) {
+        const int c = bclass[b];
+        if (c == 0) list[o0++] = b;
+        else if (c == 1) list[nblk + o1++] = b;
+    }
+    if (threadIdx.x == 0) { cnt[0] = t0; cnt[1] = t1; cnt[2] = nblk - t0 - t1; }
 }
 
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
@@ -166,8 +207,24 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
     int slots = ctx->blob_slots;
     if (slots < 1) slots = 1;
     if (slots > BLOB_S) slots = BLOB_S;
+    // decomposed runs (device API): blobs sorted into interior / boundary, so that the interior ones can run under a halo phase
+    const bool split = ctx->map_perm != nullptr && ctx->blob_split_on;
+    unsigned char* bclass = nullptr;
+    ctx->blob_split_valid = false;
+    if (split) {
+        SPHX_TRY(sphx_ensure(ctx, ctx->blob_class, (size_t)nblk));
+        SPHX_TRY(sphx_ensure(ctx, ctx->blob_split, ((size_t)2 * nblk + 4) * sizeof(int)));
+        bclass = ctx->blob_class.as<unsigned char>();
+    }
     hipLaunchKernelGGL(blob_dedup_kernel, dim3(nblk), dim3(BLOB_T), (size_t)k * BLOB_P * sizeof(u16), ctx->stream, (int)n, (int)npad, k, slots,
-                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>());
+                       ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, ctx->map_perm,
+                       ctx->map_nactive, bclass);
+    if (split) {
+        int* list = ctx->blob_split.as<int>();
+        hipLaunchKernelGGL(blob_split_kernel, dim3(1), dim3(SPLIT_T), 0, ctx->stream, nblk, bclass, list, list + 2 * (size_t)nblk);
+        ctx->blob_split_valid = true;
+        ctx->blob_split_nblk = nblk;
+    }
     HIPCHK(hipGetLastError());
     ctx->blob_lists = true;
     return SPHX_OK;
@@ -687,6 +744,13 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
 
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
+BlobSel sphx_blob_sel(sphx_ctx* ctx, int part) {
+    if (part == 0 || !ctx->blob_split_valid) return BlobSel{nullptr, nullptr};
+    const int* list = ctx->blob_split.as<int>();
+    const size_t nblk = (size_t)ctx->blob_split_nblk;
+    return BlobSel{list + (part == 2 ? nblk : 0), list + 2 * nblk + (part == 2 ? 1 : 0)};
+}
+
 int sphx_blob_grid(sphx_ctx* ctx, int nblk) {
     if (ctx->blob_grid <= 0) {
         int cus = 256;

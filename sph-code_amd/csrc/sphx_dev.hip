@@ -99,6 +99,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     ctx->map_perm = ctx->perm.as<int>();
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
+    ctx->blob_split_valid = false;
     if (ctx->use_blob) SPHX_TRY(sphx_build_blob_order(ctx, n));     // queries and passes in blob order
     ctx->map_nactive = (int)n_owned;
     ctx->n = n;
@@ -129,6 +130,17 @@ extern "C" int sphx_dev_get_order(sphx_ctx* ctx, int64_t n_total, int32_t* out) 
         return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_get_order: no search over %lld particles", (long long)n_total);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(out, ctx->map_perm, (size_t)n_total * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    return SPHX_OK;
+}
+
+extern "C" int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]) {
+    if (!ctx) return SPHX_E_ARG;
+    NEED(counts);
+    if (!ctx->blob_split_valid) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_blob_split_counts: no split (LDS passes off, or no search yet)");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(counts, ctx->blob_split.as<int>() + 2 * (size_t)ctx->blob_split_nblk, 3 * sizeof(int),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }
 

@@ -236,6 +236,12 @@ struct sphx_ctx {
     DevBuf slot16, uniq;
     bool use_lds = true;            // run the step loop's passes out of LDS (needs blob order)
     bool blob_lists = false;        // slot lists valid for the current neighbour list
+    // decomposed runs: blobs by what they need from other ranks (sphx_blob.hip: blob_dedup_kernel's bclass).
+    // blob_split: int list[2 nblk] (interior blobs from 0, boundary blobs from nblk), then cnt[3] {interior, boundary, idle}
+    DevBuf blob_class, blob_split;
+    bool blob_split_on = true, blob_split_valid = false;
+    int blob_split_nblk = 0;
+    bool loop2_interior_done = false;
     bool blob_attr_set = false;
     int blob_grid = 0;              // persistent workgroups of the LDS passes (0: not yet derived)
     int blob_slots = 1 << 20;       // distinct neighbours staged per workgroup (clamped to the image size)

@@ -680,15 +680,16 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop2_kernel(int n,
                                                                           const RecP2* __restrict__ p2,
                                                                           const double* __restrict__ m,
                                                                           const double* __restrict__ h, double* va,
-                                                                          double* vh, u64* ct_bits) {
+                                                                          double* vh, u64* ct_bits, BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, m, slot tile
     __shared__ u64 sm[PASS_T / 64];
     double* lm = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lm + BLOB_S);
     const int t = threadIdx.x / LPP, part = threadIdx.x & (LPP - 1);
     u64 mine = 0x7FF0000000000000ull;
-    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
-        const int b = xcd_block(bi, nblk);
+    const int nsel = blob_sel_count(sel, nblk);
+    for (int bi = blockIdx.x; bi < nsel; bi += gridDim.x) {
+        const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
         stage<1>(img, lm, tile, p2, m, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
@@ -812,7 +813,7 @@ static int loop_pass1_launch(sphx_ctx* ctx, int64_t n, int k, double d, StateArr
     return SPHX_OK;
 }
 // pass 2: h = each particle's OWN kNN radius (crossing time, nsc:782); an entry of 0 casts no vote
-static int loop_pass2_launch(sphx_ctx* ctx, int64_t n, int k, StateArrays& st, const double* h, u64* ct) {
+static int loop_pass2_launch(sphx_ctx* ctx, int64_t n, int k, StateArrays& st, const double* h, u64* ct, int part = 0) {
     const int npad = (int)sphx_pad64(n);
     RecP1* p1 = ctx->lrec_a.as<RecP1>(); RecP2* p2 = ctx->lrec_v.as<RecP2>();
     if (ctx->qorder && ctx->blob_lists) {
@@ -821,7 +822,7 @@ static int loop_pass2_launch(sphx_ctx* ctx, int64_t n, int k, StateArrays& st, c
         const int g = sphx_blob_grid(ctx, nblk);
         hipLaunchKernelGGL(blob_loop2_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
                            ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p1, p2,
-                           st.m.as<double>(), h, ctx->va.as<double>(), ctx->vh.as<double>(), ct);
+                           st.m.as<double>(), h, ctx->va.as<double>(), ctx->vh.as<double>(), ct, sphx_blob_sel(ctx, part));
     } else {
         hipLaunchKernelGGL(loop_pass2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, npad, k,
                            ctx->nbr.as<int>(), p1, p2, st.m.as<double>(), h, ctx->qorder, ctx->va.as<double>(),
@@ -935,6 +936,24 @@ extern "C" int sphx_dev_loop_pass1(sphx_ctx* ctx, const double* h_complete, doub
     return SPHX_OK;
 }
 
+// Pass 2 while rho_j is still travelling: the blobs none of whose particles has a ghost neighbour (blob_dedup_kernel's
+// classes) read only densities pass 1 itself left in the records.  Returns 1 when they were launched - the call of
+// sphx_dev_loop_pass2 that follows then does the boundary blobs only - and 0 when there is no such list (nothing done).
+extern "C" int sphx_dev_loop_pass2_interior(sphx_ctx* ctx) {
+    if (!ctx) return SPHX_E_ARG;
+    if (!ctx->map_perm || !(ctx->loop_d > 0.0))
+        return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_pass2_interior before sphx_dev_loop_pass1");
+    ctx->loop2_interior_done = false;
+    if (!(ctx->qorder && ctx->blob_lists && ctx->blob_split_valid)) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
+    SPHX_TRY(sphx_prime_ct(ctx, ct));
+    ctx->ct_primed = false;
+    SPHX_TRY(loop_pass2_launch(ctx, ctx->n, ctx->k, ctx->alt, ctx->alt.ax.as<double>(), ct, 1));
+    ctx->loop2_interior_done = true;
+    return 1;
+}
+
 extern "C" int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_accel, double* visc_heat,
                                    double* ct_out) {
     if (!ctx) return SPHX_E_ARG;
@@ -947,9 +966,11 @@ extern "C" int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, do
     hipLaunchKernelGGL(dev_rho_to_records_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, rho_complete,
                        ctx->lrec_v.as<RecP2>());
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
-    SPHX_TRY(sphx_prime_ct(ctx, ct));
+    const bool rest_only = ctx->loop2_interior_done;          // (the interior blobs ran, and voted their crossing times)
+    ctx->loop2_interior_done = false;
+    if (!rest_only) SPHX_TRY(sphx_prime_ct(ctx, ct));
     ctx->ct_primed = false;
-    SPHX_TRY(loop_pass2_launch(ctx, n, ctx->k, st, st.ax.as<double>(), ct));
+    SPHX_TRY(loop_pass2_launch(ctx, n, ctx->k, st, st.ax.as<double>(), ct, rest_only ? 2 : 0));
     if (visc_accel)
         hipLaunchKernelGGL(dev_to_caller_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, ctx->map_perm, ctx->map_nactive,
                            3, ctx->va.as<double>(), visc_accel);

@@ -376,6 +376,20 @@ class LibBackend:
                                                self._p(delp)))
         return rho, rhod, nden, delp
 
+    def loop_pass2_interior(self):
+        """Pass 2 of the blobs without ghost neighbours, to be called while rho_j travels (sphx_dev_loop_pass2_interior);
+        True if launched - loop_pass2 then finishes with the boundary blobs."""
+        rc = self.lib.sphx_dev_loop_pass2_interior(self.ctx.h)
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
+    def blob_split_counts(self):
+        """[interior, boundary, idle] blobs of the last search (a host read: diagnostics only)."""
+        out = (C.c_int32 * 3)()
+        self._chk(self.lib.sphx_dev_blob_split_counts(self.ctx.h, out))
+        return [int(v) for v in out]
+
     def loop_pass2(self, rho_complete):
         n, dev = self.n_total, self.device
         va = torch.empty((n, 3), dtype=torch.float64, device=dev)
@@ -479,6 +493,7 @@ class DistributedSim:
         # how much of |v_i| dt a particle adds to the reach it claims (1: a radius may grow by the particle's own displacement
         # per step; every plan is verified after the search and redone if too thin, so this only trades ghosts for redos)
         self.reach_vfac = float(os.environ.get("SPHX_REACH_VFAC", "1.0"))
+        self.overlap = os.environ.get("SPHX_MG_OVERLAP", "1") != "0"      # interior blobs' sums under the scalar halo phases
         self.plan_next = None             # the NEXT step's plan, made at the end of this one (see step)
         self.plan_ahead = True
         # coarse global grid for the need maps: global bounding box of the initial state + 25 %
@@ -869,7 +884,12 @@ class DistributedSim:
                     be.loop_prep(pos, vel, m, T, mu, gam, ptype, E_all, self.d)
                     h_done()
                     rho, rhod, nden, delp = be.loop_pass1(h)
-                    self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)  # rho_j (nsc:803)
+                    # rho_j (nsc:803) travels while pass 2 runs for the blobs without ghost neighbours
+                    rho_done = self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat,
+                                              defer=True)
+                    if self.overlap and hasattr(be, "loop_pass2_interior"):
+                        be.loop_pass2_interior()
+                    rho_done()
                     va, vh, ct = be.loop_pass2(rho)
                     ha = None
                     if self.with_drag or self.with_species:      # both read hydro_update's records (complete h)

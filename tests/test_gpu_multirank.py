@@ -128,6 +128,7 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, forms="hydro_update
         res["f_un_neighbor"] = np.ascontiguousarray(res["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
     res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
                              sim.stats.get("replans", 0)])
+    res["blob_split"] = np.array(sim.backend.blob_split_counts())
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -178,6 +179,32 @@ def test_two_ranks_redone_steps_match_oracle(tmp_path, monkeypatch):
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-11)
     assert np.max(np.abs(got["points"] - ref["points"])) <= 1e-9 * np.max(np.abs(ref["points"]))
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
+
+
+@pytest.mark.parametrize("forms", ["loop"])
+def test_two_ranks_interior_blobs_under_the_halo_phases_change_nothing(forms, tmp_path, monkeypatch):
+    """The search sorts its workgroups of 128 particles by what they need from other ranks; the sums of the interior
+    ones (no ghost among the neighbours of their owned particles) are launched while the scalar halo phase they do not
+    depend on is in flight, the boundary ones after it (SPHX_MG_OVERLAP, default on).  Same results, bit for bit, as
+    running every workgroup after the exchange."""
+    n, nsteps, world = 20000, 5, 2
+    res = {}
+    for ov in ("1", "0"):
+        monkeypatch.setenv("SPHX_MG_OVERLAP", ov)
+        out = tmp_path / ("ov" + ov)
+        out.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), n, nsteps, "uniform_cube" if forms == "loop" else "polytrope", str(out), forms),
+                 nprocs=world, join=True)
+        parts = [dict(np.load(os.path.join(str(out), "rank%d.npz" % r))) for r in range(world)]
+        order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+        res[ov] = {k_: np.concatenate([p[k_] for p in parts])[order]
+                   for k_ in ("points", "velocities", "E_internal", "sizes", "densities", "total_accel")}
+        res[ov]["dt"] = float(parts[0]["dt"])
+        split = np.array([p["blob_split"] for p in parts])
+    assert (split[:, 0] > 0).all() and (split[:, 1] > 0).all()        # both kinds of workgroup on both ranks
+    assert res["1"]["dt"] == res["0"]["dt"]
+    for k_ in ("points", "velocities", "E_internal", "sizes", "densities", "total_accel"):
+        assert np.array_equal(res["1"][k_], res["0"][k_]), k_
 
 
 @pytest.mark.parametrize("forms", ["hydro_update", "loop"])
