@@ -374,6 +374,13 @@ int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_
  * split (LDS passes off: sphx_dev_loop_pass2 does everything), < 0 on error.  Results do not depend on the split.
  * sphx_dev_blob_split_counts: {interior, boundary, idle} blobs of the last search (a device-to-host read: diagnostics). */
 int sphx_dev_loop_pass2_interior(sphx_ctx* ctx);
+/* The same overlap for hydro_update's sums.  sphx_dev_select_blobs(part): the calls of sphx_dev_prep / _density / _pi /
+ * _visc that follow work on  1: the interior blobs (prep: the owned particles' records),  2: the boundary blobs (prep:
+ * the ghosts' records),  0: everything (the default after every sphx_dev_search).  A pass is then called twice with the
+ * same output arrays: part 1 while the halo phase it does not depend on is in flight (ghost entries of its *_complete
+ * input are not read), part 2 after it.  Returns 1 if the selection is in force, 0 if there is no split (the selection
+ * stays "everything": do not call a pass twice), < 0 on error. */
+int sphx_dev_select_blobs(sphx_ctx* ctx, int part);
 int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]);
 /* drv:460-491 on those outputs: pressure_accel = delp / rho [gas], visc_accel = av[0].  red2 == NULL: the step `dt`;
  * else verdict and dt on the device as sphx_dev_integrate_auto (dt_out required).                                       */

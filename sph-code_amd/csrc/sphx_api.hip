@@ -474,6 +474,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
     ctx->blob_split_valid = false;
+    ctx->pass_part = 0;
     ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
     if (rec0) HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238: applied by the grid build's first pass over the particles (sphx_grid.hip); the Verlet path looks at

@@ -284,13 +284,14 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int 
                                                               const int* __restrict__ omap, int n_active,
                                                               const RecA* __restrict__ rec, double* rho_s,
                                                               double* rho, double* rhod, double* nden, double* G,
-                                                              double* ha) {
+                                                              double* ha, BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
     u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
     const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     // persistent workgroups (two per CU): blob after blob, no dispatch gap between them
-    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
-        const int b = xcd_block(bi, nblk);
+    const int nsel = blob_sel_count(sel, nblk);
+    for (int bi = blockIdx.x; bi < nsel; bi += gridDim.x) {
+        const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
         if (EXP != 2)
@@ -392,15 +393,16 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_pi_kernel(int n, in
                                                          const RecB* __restrict__ recb,
                                                          const double* __restrict__ rho_s,
                                                          const RecSelf* __restrict__ selfr, RecBC* bc, double* Pi,
-                                                         double* BwOut, u64* ct_bits) {
+                                                         double* BwOut, u64* ct_bits, BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, BLOB_S doubles, slot tile
     __shared__ u64 sm[PASS_T / 64];
     double* lrho = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lrho + BLOB_S);
     const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     u64 my_ct = 0x7FF0000000000000ull;       // +inf: "no crossing time"
-    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
-        const int b = xcd_block(bi, nblk);
+    const int nsel = blob_sel_count(sel, nblk);
+    for (int bi = blockIdx.x; bi < nsel; bi += gridDim.x) {
+        const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
         stage<1>(img, lrho, tile, recb, rho_s, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
@@ -518,14 +520,16 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, 
                                                            const int* __restrict__ omap, int n_active,
                                                            const RecB* __restrict__ recb,
                                                            const RecBC* __restrict__ bc,
-                                                           const double* __restrict__ m, double* va, double* vh) {
+                                                           const double* __restrict__ m, double* va, double* vh,
+                                                           BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks {x y | z h2 | vx vy | vz Bw}, c1, tile
     double* lc1 = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lc1 + BLOB_S);
     const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);     // half: which partial sum
     const double* bcd = reinterpret_cast<const double*>(bc);
-    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
-        const int b = xcd_block(bi, nblk);
+    const int nsel = blob_sel_count(sel, nblk);
+    for (int bi = blockIdx.x; bi < nsel; bi += gridDim.x) {
+        const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
         stage<2>(img, lc1, tile, recb, bcd, 2, bcd + 1, 2, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
@@ -795,7 +799,8 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
 #define BLOB_EXP_LAUNCH(M)                                                                                           \
             hipLaunchKernelGGL(blob_density_kernel<M>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
                                k, nblk, ctx->clip_grad, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, \
-                               nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n)
+                               nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n, \
+                               BlobSel{nullptr, nullptr})
             if (mode == 0) BLOB_EXP_LAUNCH(0);
             else if (mode == 1) BLOB_EXP_LAUNCH(1);
             else if (mode == 2) BLOB_EXP_LAUNCH(2);
@@ -812,7 +817,8 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->rho.as<double>(),
-                       ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>());
+                       ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>(),
+                       sphx_blob_sel(ctx, ctx->pass_part));
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -825,7 +831,7 @@ int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits) {
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->rho_s.as<double>(), ctx->self_s.as<RecSelf>(), ctx->bc_s.as<RecBC>(), ctx->Pi.as<double>(),
-                       ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct_bits);
+                       ctx->map_perm ? ctx->Bw.as<double>() : nullptr, ct_bits, sphx_blob_sel(ctx, ctx->pass_part));
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -838,7 +844,7 @@ int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m) {
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->recv.as<RecB>(),
                        ctx->bc_s.as<RecBC>(), m, ctx->va.as<double>(),
-                       ctx->vh.as<double>());
+                       ctx->vh.as<double>(), sphx_blob_sel(ctx, ctx->pass_part));
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

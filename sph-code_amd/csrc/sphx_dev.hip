@@ -100,6 +100,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
     ctx->blob_split_valid = false;
+    ctx->pass_part = 0;
     if (ctx->use_blob) SPHX_TRY(sphx_build_blob_order(ctx, n));     // queries and passes in blob order
     ctx->map_nactive = (int)n_owned;
     ctx->n = n;
@@ -131,6 +132,16 @@ extern "C" int sphx_dev_get_order(sphx_ctx* ctx, int64_t n_total, int32_t* out) 
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(out, ctx->map_perm, (size_t)n_total * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     return SPHX_OK;
+}
+
+extern "C" int sphx_dev_select_blobs(sphx_ctx* ctx, int part) {
+    if (!ctx) return SPHX_E_ARG;
+    if (part < 0 || part > 2) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_dev_select_blobs: part %d not in 0..2", part);
+    ctx->pass_part = 0;
+    if (part == 0) return 0;
+    if (!(ctx->map_perm && ctx->qorder && ctx->blob_lists && ctx->blob_split_valid)) return 0;
+    ctx->pass_part = part;
+    return 1;
 }
 
 extern "C" int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]) {
@@ -191,9 +202,13 @@ extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_pi before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = ctx->n;
-    hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->map_perm, rho_complete, ctx->rho_s.as<double>(), 1);
+    // (interior blobs: every density they read was left in sorted order by pass 1 itself; boundary blobs after the
+    //  interior ones: the crossing-time votes already cast are kept)
+    if (ctx->pass_part != 1)
+        hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           ctx->map_perm, rho_complete, ctx->rho_s.as<double>(), 1);
     HIPCHK(hipGetLastError());
+    if (ctx->pass_part == 2) ctx->ct_primed = true;
     {
         Borrow b1(ctx->Pi, Pi, (size_t)n * sizeof(double)), b2(ctx->Bw, Bw, (size_t)n * sizeof(double));
         SPHX_TRY(sphx_pass_pi(ctx, n, ctx->k, nullptr, nullptr));
@@ -210,8 +225,9 @@ extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const dou
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_visc before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = ctx->n;
-    hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->map_perm, Bw_complete, ctx->bc_s.as<double>(), 2);
+    if (ctx->pass_part != 1)          // (interior blobs: pass 2 left every m Pi they read in the sorted records)
+        hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           ctx->map_perm, Bw_complete, ctx->bc_s.as<double>(), 2);
     HIPCHK(hipGetLastError());
     Borrow b1(ctx->va, visc_accel, 3 * (size_t)n * sizeof(double)), b2(ctx->vh, visc_heat, (size_t)n * sizeof(double));
     SPHX_TRY(sphx_pass_visc(ctx, n, ctx->k, mass));

@@ -242,6 +242,7 @@ struct sphx_ctx {
     bool blob_split_on = true, blob_split_valid = false;
     int blob_split_nblk = 0;
     bool loop2_interior_done = false;
+    int pass_part = 0;              // which blobs hydro_update's passes and the record build take: 0 all, 1 interior, 2 boundary
     bool blob_attr_set = false;
     int blob_grid = 0;              // persistent workgroups of the LDS passes (0: not yet derived)
     int blob_slots = 1 << 20;       // distinct neighbours staged per workgroup (clamped to the image size)

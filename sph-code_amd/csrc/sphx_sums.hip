@@ -26,12 +26,14 @@ struct PrepArgs {
     double kB, amu;
     RecA* ra; RecB* rb; RecBC* bc; RecSelf* self;
     const int* perm;                       // sorted -> caller index of the inputs (nullptr: identity)
+    int which, n_active;                   // decomposed runs: 0 every particle, 1 the owned ones (perm < n_active), 2 the ghosts
 };
 
 __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n) return;
     const int i = a.perm ? a.perm[t] : t;
+    if (a.which && ((i < a.n_active) != (a.which == 1))) return;
     const double m = a.m[i], h = a.h[i], T = a.T[i], mu = a.mu[i], gam = a.gam[i], pt = a.ptype[i];
     const double g = (pt == 0.0) ? 1.0 : 0.0;
     RecA r; RecB v;
@@ -78,6 +80,8 @@ int sphx_prep(sphx_ctx* ctx, int64_t n, const double* x, const double* y, const 
     a.bc = ctx->bc_s.as<RecBC>();
     a.self = ctx->self_s.as<RecSelf>();
     a.perm = ctx->map_perm;
+    a.which = ctx->map_perm ? ctx->pass_part : 0;
+    a.n_active = ctx->map_nactive;
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;

@@ -284,28 +284,46 @@ class LibBackend:
         self._keep = (pos, vel, m, h, T, mu, gam, ptype)
         self._chk(self.lib.sphx_dev_prep(self.ctx.h, *[self._p(t) for t in self._keep]))
 
-    def density(self, want_dust=False):
+    def select_blobs(self, part):
+        """The passes that follow take: 1 the interior blobs (no ghost among their particles' neighbours; prep: the owned
+        particles' records), 2 the boundary blobs (prep: the ghosts'), 0 everything.  True if in force (sphx_dev_select_blobs);
+        a pass is then called once per part with the same output arrays (out=)."""
+        rc = self.lib.sphx_dev_select_blobs(self.ctx.h, int(part))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
+    def density(self, want_dust=False, out=None):
         n, dev = self.n_total, self.device
         # the passes write every owned particle's entry straight into these (no copy); ghosts' entries are
         # either filled by the halo exchange (rho, m Pi) or never read
-        rho = torch.empty(n, dtype=torch.float64, device=dev)
-        nden = torch.empty(n, dtype=torch.float64, device=dev)
-        ha = torch.empty((n, 3), dtype=torch.float64, device=dev)
-        self.rhod = torch.empty(n, dtype=torch.float64, device=dev) if want_dust else None
+        if out is None:
+            rho = torch.empty(n, dtype=torch.float64, device=dev)
+            nden = torch.empty(n, dtype=torch.float64, device=dev)
+            ha = torch.empty((n, 3), dtype=torch.float64, device=dev)
+            self.rhod = torch.empty(n, dtype=torch.float64, device=dev) if want_dust else None
+        else:
+            rho, nden, ha = out
         self._chk(self.lib.sphx_dev_density(self.ctx.h, self._p(rho), self._p(self.rhod), self._p(nden), self._p(ha)))
         return rho, nden, ha
 
-    def pi(self, rho_complete):
+    def pi(self, rho_complete, out=None):
         n, dev = self.n_total, self.device
-        bw = torch.empty(n, dtype=torch.float64, device=dev)
-        ct = torch.zeros(1, dtype=torch.float64, device=dev)
+        if out is None:
+            bw = torch.empty(n, dtype=torch.float64, device=dev)
+            ct = torch.zeros(1, dtype=torch.float64, device=dev)
+        else:
+            bw, ct = out
         self._chk(self.lib.sphx_dev_pi(self.ctx.h, self._p(rho_complete), None, self._p(bw), self._p(ct)))
         return bw, ct
 
-    def visc(self, bw_complete, m):
+    def visc(self, bw_complete, m, out=None):
         n, dev = self.n_total, self.device
-        va = torch.empty((n, 3), dtype=torch.float64, device=dev)
-        vh = torch.empty(n, dtype=torch.float64, device=dev)
+        if out is None:
+            va = torch.empty((n, 3), dtype=torch.float64, device=dev)
+            vh = torch.empty(n, dtype=torch.float64, device=dev)
+        else:
+            va, vh = out
         self._chk(self.lib.sphx_dev_visc(self.ctx.h, self._p(bw_complete), self._p(m), self._p(va), self._p(vh)))
         return va, vh
 
@@ -897,13 +915,34 @@ class DistributedSim:
                     self._step_extras(be, no, ng, send_idx, recv_counts, m, ptype, extra, rho, rhod)
             else:
               with self._sec("sums+halo_scalars"):
-                self._exchange(send_idx, recv_counts, [h[:no]], into=tail(h), send_cat=self.send_cat)        # h_j
-                be.prep(pos, vel, m, h, T, mu, gam, ptype)
-                rho, nden, ha = be.density(True) if self.with_drag else be.density()
-                self._exchange(send_idx, recv_counts, [rho[:no]], into=tail(rho), send_cat=self.send_cat)    # rho_j
-                bw, ct = be.pi(rho)
-                self._exchange(send_idx, recv_counts, [bw[:no]], into=tail(bw), send_cat=self.send_cat)      # m Pi_j
-                va, vh = be.visc(bw, m)
+                xch = lambda a, defer=False: self._exchange(send_idx, recv_counts, [a[:no]], into=tail(a), send_cat=self.send_cat,
+                                                            defer=defer)
+                if self.overlap and self.world > 1 and hasattr(be, "select_blobs") and be.select_blobs(1):
+                    # every scalar phase travels while the pass that follows it runs for the blobs whose particles have
+                    # no ghost neighbour (they read nothing the phase delivers); the boundary blobs run after it
+                    done = xch(h, True)                                        # h_j
+                    be.prep(pos, vel, m, h, T, mu, gam, ptype)                 # (owned particles' records)
+                    o1 = be.density(self.with_drag)
+                    done(); be.select_blobs(2)
+                    be.prep(pos, vel, m, h, T, mu, gam, ptype)                 # (ghosts' records)
+                    rho, nden, ha = be.density(self.with_drag, out=o1)
+                    done = xch(rho, True); be.select_blobs(1)                  # rho_j
+                    o2 = be.pi(rho)
+                    done(); be.select_blobs(2)
+                    bw, ct = be.pi(rho, out=o2)
+                    done = xch(bw, True); be.select_blobs(1)                   # m Pi_j
+                    o3 = be.visc(bw, m)
+                    done(); be.select_blobs(2)
+                    va, vh = be.visc(bw, m, out=o3)
+                    be.select_blobs(0)
+                else:
+                    xch(h)                                                     # h_j
+                    be.prep(pos, vel, m, h, T, mu, gam, ptype)
+                    rho, nden, ha = be.density(True) if self.with_drag else be.density()
+                    xch(rho)                                                   # rho_j
+                    bw, ct = be.pi(rho)
+                    xch(bw)                                                    # m Pi_j
+                    va, vh = be.visc(bw, m)
                 self._step_extras(be, no, ng, send_idx, recv_counts, m, ptype, extra, rho,
                                   getattr(be, "rhod", None) if self.with_drag else None)
             # ---- ONE reduction and ONE host read for the step's scalars: halo verdict (max), global

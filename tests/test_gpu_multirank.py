@@ -181,7 +181,7 @@ def test_two_ranks_redone_steps_match_oracle(tmp_path, monkeypatch):
     assert np.max(np.abs(got["velocities"] - ref["velocities"])) <= 1e-9 * np.max(np.abs(ref["velocities"]))
 
 
-@pytest.mark.parametrize("forms", ["loop"])
+@pytest.mark.parametrize("forms", ["hydro_update", "loop"])
 def test_two_ranks_interior_blobs_under_the_halo_phases_change_nothing(forms, tmp_path, monkeypatch):
     """The search sorts its workgroups of 128 particles by what they need from other ranks; the sums of the interior
     ones (no ghost among the neighbours of their owned particles) are launched while the scalar halo phase they do not
