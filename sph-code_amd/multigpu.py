@@ -1186,6 +1186,16 @@ def decompose_state(state, world, rank):
 # ==============================================================================================
 # bench leg for N > 1 (called by bench.py under torch.distributed.run)
 # ==============================================================================================
+def _blob_split(be, sim):
+    if not (getattr(sim, "overlap", False) and hasattr(be, "blob_split_counts")):
+        return None
+    try:
+        c = be.blob_split_counts()
+    except RuntimeError:
+        return None
+    return {"interior": c[0], "boundary": c[1], "idle": c[2], "overlap": "on" if sim.world > 1 else "one rank: nothing to overlap"}
+
+
 def bench_main(args, rank, local_rank, world):
     from . import ics
     if not torch.cuda.is_available():
@@ -1310,7 +1320,10 @@ def bench_main(args, rank, local_rank, world):
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
                      "search_redos": float(cnt[3]),
                      "replans_per_step_rank0": sim.stats.get("replans", 0) / max(args.steps, 1),
-                     "migrated_rank0": sim.stats.get("migrated", 0)},
+                     "migrated_rank0": sim.stats.get("migrated", 0),
+                     # workgroups of 128 particles by what they need from other ranks (last step, rank 0): the sums of the
+                     # interior ones run under the scalar halo phases
+                     "blobs_rank0": _blob_split(be, sim)},
             # rank 0's host wall time per step by section of DistributedSim.step (no added syncs: GPU
             # work is charged to the section whose host code next waits for it)
             "host_ms_per_step_rank0": {k_: v / max(args.steps, 1) for k_, v in sorted(sim.host_ms.items())},

@@ -1,7 +1,7 @@
 """Rank 0's GPU timeline around the sums of one step, from tools/overlap_trace.sh's rocprofv3 kernel trace:
    python3 tools/overlap_timeline.py gpurun_out/ovt_<tag> profiles/<tag>_overlap_timeline.json [anchor-kernel-prefix]
-Takes the LAST step of the run: from the first launch of the sums (loop forms: blob_loop1_kernel; hydro_update:
-prep_kernel) to the last output kernel after the last blob pass.  Host<->device copies of the halo appear as
+Takes the LAST step of the run: from the launch that follows the search (blob_dedup_kernel, which also sorts the
+workgroups into interior / boundary) to the last output kernel after the last blob pass.  Host<->device copies of the halo appear as
 __amd_rocclr_copyBuffer launches (the gloo rehearsal moves the halo through host memory)."""
 import csv
 import json
@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(os.path.join(src, "prof", "r0_kernel_trace.csv")
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda nm: nm.split("(")[0].replace("void ", "")[:48]
 names = [short(r["Kernel_Name"]) for r in rows]
-anchor = sys.argv[3] if len(sys.argv) > 3 else ("blob_loop1_kernel" if any(n.startswith("blob_loop1") for n in names) else "prep_kernel")
+anchor = sys.argv[3] if len(sys.argv) > 3 else "blob_dedup_kernel"
 starts = [i for i, n in enumerate(names) if n.startswith(anchor)]
 i0 = starts[-1]
 blob = [i for i, n in enumerate(names) if n.startswith("blob_") and i >= i0 and not n.startswith(("blob_dedup", "blob_split", "blob_count"))]
