@@ -145,13 +145,18 @@ __device__ __forceinline__ bool all_staged(const unsigned (&sl)[NB]) {
 
 // The blobs a launch works through: all nblk of them, or one of blob_split_kernel's lists (decomposed runs: the
 // interior blobs while a halo phase is in flight, the boundary blobs after it) - its length read from device memory.
-struct BlobSel { const int* list; const int* cnt; };
-__device__ __forceinline__ int blob_sel_count(const BlobSel& s, int nblk) { return s.list ? *s.cnt : nblk; }
+// list: interior blobs, then boundary blobs (each in blob order); cnt = {interior, boundary, idle}.
+// mode 1: the interior ones, 2: the boundary ones, 3: both (every blob with something to compute).
+struct BlobSel { const int* list; const int* cnt; int mode; };
+__device__ __forceinline__ int blob_sel_count(const BlobSel& s, int nblk) {
+    if (!s.list) return nblk;
+    return (s.mode == 1) ? s.cnt[0] : (s.mode == 2) ? s.cnt[1] : s.cnt[0] + s.cnt[1];
+}
 __device__ __forceinline__ int blob_sel_at(const BlobSel& s, int bi, int count) {
     const int q = xcd_block(bi, count);
-    return s.list ? s.list[q] : q;
+    return s.list ? s.list[q + (s.mode == 2 ? s.cnt[0] : 0)] : q;
 }
-// part: 0 all blobs, 1 the interior ones, 2 the boundary ones (needs ctx->blob_split_valid)
+// part: 0 all blobs (with a valid split: all but the idle ones), 1 the interior ones, 2 the boundary ones
 BlobSel sphx_blob_sel(sphx_ctx* ctx, int part);
 
 int sphx_blob_grid(sphx_ctx* ctx, int nblk);       // persistent grid of the LDS passes (2 workgroups per CU)

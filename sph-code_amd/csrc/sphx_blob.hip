@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
     }
 }
 
-// interior blobs, then boundary blobs, each in blob order: list[0 .. cnt[0]) and list[nblk .. nblk + cnt[1]).
+// interior blobs, then boundary blobs, each in blob order: list[0 .. cnt[0]) and list[cnt[0] .. cnt[0] + cnt[1]).
 // One workgroup (a few thousand blobs per 10^6 particles); each thread takes a run of consecutive blobs.
 #define SPLIT_T 1024
 __global__ __launch_bounds__(SPLIT_T) void blob_split_kernel(int nblk, const unsigned char* __restrict__ bclass, int* list,
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SPLIT_T) void blob_split_kernel(int nblk, const uns
     for (int b = b0; b < b1; ++b) {
         const int c = bclass[b];
         if (c == 0) list[o0++] = b;
-        else if (c == 1) list[nblk + o1++] = b;
+        else if (c == 1) list[t0 + o1++] = b;
     }
     if (threadIdx.x == 0) { cnt[0] = t0; cnt[1] = t1; cnt[2] = nblk - t0 - t1; }
 }
@@ -213,7 +213,7 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
     ctx->blob_split_valid = false;
     if (split) {
         SPHX_TRY(sphx_ensure(ctx, ctx->blob_class, (size_t)nblk));
-        SPHX_TRY(sphx_ensure(ctx, ctx->blob_split, ((size_t)2 * nblk + 4) * sizeof(int)));
+        SPHX_TRY(sphx_ensure(ctx, ctx->blob_split, ((size_t)nblk + 4) * sizeof(int)));
         bclass = ctx->blob_class.as<unsigned char>();
     }
     hipLaunchKernelGGL(blob_dedup_kernel, dim3(nblk), dim3(BLOB_T), (size_t)k * BLOB_P * sizeof(u16), ctx->stream, (int)n, (int)npad, k, slots,
@@ -221,7 +221,7 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
                        ctx->map_nactive, bclass);
     if (split) {
         int* list = ctx->blob_split.as<int>();
-        hipLaunchKernelGGL(blob_split_kernel, dim3(1), dim3(SPLIT_T), 0, ctx->stream, nblk, bclass, list, list + 2 * (size_t)nblk);
+        hipLaunchKernelGGL(blob_split_kernel, dim3(1), dim3(SPLIT_T), 0, ctx->stream, nblk, bclass, list, list + (size_t)nblk);
         ctx->blob_split_valid = true;
         ctx->blob_split_nblk = nblk;
     }
@@ -749,10 +749,9 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
 BlobSel sphx_blob_sel(sphx_ctx* ctx, int part) {
-    if (part == 0 || !ctx->blob_split_valid) return BlobSel{nullptr, nullptr};
+    if (!ctx->blob_split_valid) return BlobSel{nullptr, nullptr, 0};
     const int* list = ctx->blob_split.as<int>();
-    const size_t nblk = (size_t)ctx->blob_split_nblk;
-    return BlobSel{list + (part == 2 ? nblk : 0), list + 2 * nblk + (part == 2 ? 1 : 0)};
+    return BlobSel{list, list + (size_t)ctx->blob_split_nblk, part == 0 ? 3 : part};
 }
 
 int sphx_blob_grid(sphx_ctx* ctx, int nblk) {
@@ -800,7 +799,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             hipLaunchKernelGGL(blob_density_kernel<M>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), lds, ctx->stream, (int)n, (int)npad, \
                                k, nblk, ctx->clip_grad, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, \
                                nullptr, (int)n, ctx->rec1.as<RecA>(), d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 8 * n, \
-                               BlobSel{nullptr, nullptr})
+                               BlobSel{nullptr, nullptr, 0})
             if (mode == 0) BLOB_EXP_LAUNCH(0);
             else if (mode == 1) BLOB_EXP_LAUNCH(1);
             else if (mode == 2) BLOB_EXP_LAUNCH(2);

@@ -149,7 +149,7 @@ extern "C" int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]) {
     NEED(counts);
     if (!ctx->blob_split_valid) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_blob_split_counts: no split (LDS passes off, or no search yet)");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(counts, ctx->blob_split.as<int>() + 2 * (size_t)ctx->blob_split_nblk, 3 * sizeof(int),
+    HIPCHK(hipMemcpyAsync(counts, ctx->blob_split.as<int>() + (size_t)ctx->blob_split_nblk, 3 * sizeof(int),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;

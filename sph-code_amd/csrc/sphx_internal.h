@@ -237,7 +237,7 @@ struct sphx_ctx {
     bool use_lds = true;            // run the step loop's passes out of LDS (needs blob order)
     bool blob_lists = false;        // slot lists valid for the current neighbour list
     // decomposed runs: blobs by what they need from other ranks (sphx_blob.hip: blob_dedup_kernel's bclass).
-    // blob_split: int list[2 nblk] (interior blobs from 0, boundary blobs from nblk), then cnt[3] {interior, boundary, idle}
+    // blob_split: int list[nblk] (interior blobs, then boundary blobs), then cnt[3] {interior, boundary, idle}
     DevBuf blob_class, blob_split;
     bool blob_split_on = true, blob_split_valid = false;
     int blob_split_nblk = 0;

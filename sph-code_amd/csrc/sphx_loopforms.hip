@@ -606,13 +606,14 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
                                                                           const double* __restrict__ m,
                                                                           const double* __restrict__ h, double* rho,
                                                                           double* rhod, double* nden, double* G,
-                                                                          RecP2* p2) {
+                                                                          RecP2* p2, BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, gamma, slot tile
     double* lgam = reinterpret_cast<double*>(img + 4 * BLOB_S);
     u16* tile = reinterpret_cast<u16*>(lgam + BLOB_S);
     const int t = threadIdx.x / LPP, part = threadIdx.x & (LPP - 1);
-    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
-        const int b = xcd_block(bi, nblk);
+    const int nsel = blob_sel_count(sel, nblk);
+    for (int bi = blockIdx.x; bi < nsel; bi += gridDim.x) {
+        const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
         stage<1>(img, lgam, tile, p1, gam, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
@@ -802,7 +803,8 @@ static int loop_pass1_launch(sphx_ctx* ctx, int64_t n, int k, double d, StateArr
         hipLaunchKernelGGL(blob_loop1_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
                            d9, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p1,
                            st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(), h,
-                           ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), p2);
+                           ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), p2,
+                           sphx_blob_sel(ctx, 0));
     } else {
         hipLaunchKernelGGL(loop_pass1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, npad, k, d9,
                            ctx->nbr.as<int>(), p1, st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(),

@@ -1207,6 +1207,9 @@ def bench_main(args, rank, local_rank, world):
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if world == 1:                               # (SPHX_FORCE_DIST=1 without a launcher: a rendezvous with itself)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         comm_dev = dev
