@@ -89,6 +89,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
     if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
@@ -475,6 +476,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     ctx->blob_lists = false;
     ctx->blob_split_valid = false;
     ctx->pass_part = 0;
+    SPHX_TRY(sphx_blob_join(ctx));   // (a context that also serves the device API: its side-stream work ends first)
     ctx->nbr_api_valid = false;   // the step overwrites the K-major list (search or Verlet refresh)
     if (rec0) HIPCHK(hipEventRecord(ev[0], ctx->stream));
     // drv:233-238: applied by the grid build's first pass over the particles (sphx_grid.hip); the Verlet path looks at

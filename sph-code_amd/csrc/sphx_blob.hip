@@ -748,6 +748,14 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
 
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
+int sphx_blob_join(sphx_ctx* ctx) {
+    if (ctx->dedup_pending) {
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        ctx->dedup_pending = false;
+    }
+    return SPHX_OK;
+}
+
 BlobSel sphx_blob_sel(sphx_ctx* ctx, int part) {
     if (!ctx->blob_split_valid) return BlobSel{nullptr, nullptr, 0};
     const int* list = ctx->blob_split.as<int>();

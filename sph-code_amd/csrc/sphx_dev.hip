@@ -73,6 +73,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
                             (long long)n_owned);
     if (k < 1 || k > SPHX_MAX_K) return sphx_set_err(ctx, SPHX_E_ARG, "N_NEIGH=%d not in 1..%d", k, SPHX_MAX_K);
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));                 // (a search whose lists nobody used: they are rebuilt below)
     SPHX_TRY(sphx_dev_collect(ctx));
     const int64_t n = n_total;
     const size_t nb = (size_t)n * sizeof(double);
@@ -119,7 +120,23 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     ctx->knn_hinted = false;
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->dev_ev_pending = (rc == SPHX_OK);
-    if (rc == SPHX_OK && ctx->qorder && ctx->use_lds) rc = sphx_blob_translate(ctx, n, k);
+    if (rc == SPHX_OK && ctx->qorder && ctx->use_lds) {
+        if (ctx->side_stream && ctx->ev_join && ctx->dev_fork_dedup) {
+            // the slot lists (0.11 ms of LDS bookkeeping) are built on the side stream, beside whatever the caller does
+            // between the search and the first pass: the record build, the h_j halo phase
+            hipStream_t main_stream = ctx->stream;
+            HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev[2], 0));
+            ctx->stream = ctx->side_stream;
+            rc = sphx_blob_translate(ctx, n, k);
+            ctx->stream = main_stream;
+            if (rc == SPHX_OK) {
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+                ctx->dedup_pending = true;
+            }
+        } else {
+            rc = sphx_blob_translate(ctx, n, k);
+        }
+    }
     return rc;
 }
 
@@ -149,6 +166,7 @@ extern "C" int sphx_dev_blob_split_counts(sphx_ctx* ctx, int32_t counts[3]) {
     NEED(counts);
     if (!ctx->blob_split_valid) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_blob_split_counts: no split (LDS passes off, or no search yet)");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     HIPCHK(hipMemcpyAsync(counts, ctx->blob_split.as<int>() + (size_t)ctx->blob_split_nblk, 3 * sizeof(int),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -190,6 +208,7 @@ extern "C" int sphx_dev_density(sphx_ctx* ctx, double* rho, double* rho_dust, do
     if (!ctx) return SPHX_E_ARG;
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_density before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const size_t nb = (size_t)ctx->n * sizeof(double);
     Borrow b1(ctx->rho, rho, nb), b2(ctx->rhod, rho_dust, nb), b3(ctx->nden, nden, nb), b4(ctx->ha, hydro_accel, 3 * nb);
     SPHX_TRY(sphx_pass_density(ctx, ctx->n, ctx->k));
@@ -201,6 +220,7 @@ extern "C" int sphx_dev_pi(sphx_ctx* ctx, const double* rho_complete, double* Pi
     NEED(rho_complete);
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_pi before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     // (interior blobs: every density they read was left in sorted order by pass 1 itself; boundary blobs after the
     //  interior ones: the crossing-time votes already cast are kept)
@@ -224,6 +244,7 @@ extern "C" int sphx_dev_visc(sphx_ctx* ctx, const double* Bw_complete, const dou
     NEED(Bw_complete); NEED(mass);
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_visc before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     if (ctx->pass_part != 1)          // (interior blobs: pass 2 left every m Pi they read in the sorted records)
         hipLaunchKernelGGL(inject_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
@@ -429,6 +450,7 @@ extern "C" int sphx_dev_drag(sphx_ctx* ctx, const double* mass, const double* pt
     NEED(mass); NEED(ptype); NEED(mean_grain_mass); NEED(mean_cross); NEED(drag_on); NEED(drag_reaction);
     if (!ctx->map_perm) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_drag before sphx_dev_search");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     const unsigned grid = (unsigned)((n + 255) / 256);
     StateArrays& st = ctx->alt;
@@ -489,6 +511,7 @@ extern "C" int sphx_dev_species(sphx_ctx* ctx, int nspecies, const double* f_un,
     if ((Z || agb_dust) && !(ctx->agb_on && Z && agb_dust && ctx->agb.nspec == nspecies))
         return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_species: Z / agb_dust need both pointers and a table for %d species", nspecies);
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     const int S = nspecies, SP = (S + 15) & ~15;
     const unsigned grid = (unsigned)((n + 255) / 256);

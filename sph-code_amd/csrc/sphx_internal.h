@@ -242,6 +242,11 @@ struct sphx_ctx {
     bool blob_split_on = true, blob_split_valid = false;
     int blob_split_nblk = 0;
     bool loop2_interior_done = false;
+    bool dedup_pending = false;     // device API: the dedup of the last search runs on the side stream (joined by sphx_blob_join)
+    // (off: measured at one rank, 10^6 particles - dedup 109 -> 169 us and the record build 73 -> 95 us when they run side
+    //  by side, both HBM-bound: the pair takes the 182 us it takes back to back.  SPHX_DEV_FORK_DEDUP=1 to try it where
+    //  the main stream would otherwise wait for the network between the search and the first pass)
+    bool dev_fork_dedup = false;
     int pass_part = 0;              // which blobs hydro_update's passes and the record build take: 0 all, 1 interior, 2 boundary
     bool blob_attr_set = false;
     int blob_grid = 0;              // persistent workgroups of the LDS passes (0: not yet derived)
@@ -378,6 +383,8 @@ int sphx_dev_collect(sphx_ctx* ctx);
 int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d);
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
+// device API: the main stream waits for the slot lists of the last search (built beside the record build / the h_j phase)
+int sphx_blob_join(sphx_ctx* ctx);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits);
 int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);

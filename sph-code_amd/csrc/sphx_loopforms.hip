@@ -919,6 +919,7 @@ extern "C" int sphx_dev_loop_pass1(sphx_ctx* ctx, const double* h_complete, doub
     NEEDD(h_complete);
     if (!ctx->map_perm || !(ctx->loop_d > 0.0)) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_pass1 before sphx_dev_loop_prep");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     const unsigned grid = (unsigned)((n + 255) / 256);
     StateArrays& st = ctx->alt;
@@ -948,6 +949,7 @@ extern "C" int sphx_dev_loop_pass2_interior(sphx_ctx* ctx) {
     ctx->loop2_interior_done = false;
     if (!(ctx->qorder && ctx->blob_lists && ctx->blob_split_valid)) return 0;
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     u64* ct = ctx->scal.as<u64>() + SC_CT_BITS;
     SPHX_TRY(sphx_prime_ct(ctx, ct));
     ctx->ct_primed = false;
@@ -962,6 +964,7 @@ extern "C" int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, do
     NEEDD(rho_complete);
     if (!ctx->map_perm || !(ctx->loop_d > 0.0)) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_dev_loop_pass2 before sphx_dev_loop_prep");
     HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_blob_join(ctx));
     const int64_t n = ctx->n;
     const unsigned grid = (unsigned)((n + 255) / 256);
     StateArrays& st = ctx->alt;
