@@ -210,18 +210,49 @@ class LibBackend:
             self._chk(self.lib.sphx_dev_pack_rows(self.ctx.h, n, self._p(idx), len(fields), arr, wid, self._p(rows)))
         return rows
 
+    SLACK = 0.3      # room behind a rank's owned arrays for its ghosts (append_rows), as a fraction of the owned count
+
     def regroup(self, sel, n_sel, rows, fields):
-        """New arrays: fields[sel] followed by the particles in `rows` (one launch; sphx_dev_regroup)."""
+        """New arrays: fields[sel] followed by the particles in `rows` (one launch; sphx_dev_regroup).  Each comes with
+        room behind it (SLACK), so that append_rows can put the step's ghosts there without copying the owned part."""
         fields = [f.contiguous() for f in fields]
         nr = 0 if rows is None else int(rows.shape[0])
         n = n_sel + nr
-        outs = [torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=self.device) for f in fields]
+        cap = n + int(self.SLACK * n) + 1024
+        outs = [torch.empty((cap,) + tuple(f.shape[1:]), dtype=f.dtype, device=self.device)[:n] for f in fields]
         if n:
             arr, wid = self._table(fields)
             oarr, _ = self._table(outs)
             self._chk(self.lib.sphx_dev_regroup(self.ctx.h, n_sel, self._p(sel), nr,
                                                 self._p(rows.contiguous()) if nr else None, len(fields), arr, wid, oarr))
         return outs
+
+    def append_rows(self, n_owned, rows, fields):
+        """The owned arrays `fields` ((n_owned,) or (n_owned, w), float64) with the particles in `rows` appended IN PLACE:
+        -> (complete, owned), complete[q] = the (n_owned + len(rows), ...) array whose first n_owned entries are the
+        storage of owned[q].  Where a field's storage has room behind the owned part (arrays made by regroup, or by an
+        earlier call) nothing but the new rows is written; otherwise the field moves once to a roomier buffer and
+        owned[q] is the new owned view, which the caller keeps in place of the old one."""
+        nr = 0 if rows is None else int(rows.shape[0])
+        need = n_owned + nr
+        complete, owned = [], []
+        for f in fields:
+            w = 1 if f.dim() == 1 else int(f.shape[1])
+            st = f.untyped_storage()
+            room = (st.nbytes() // f.element_size() - f.storage_offset()) // w
+            if f.is_contiguous() and int(f.shape[0]) == n_owned and room >= need:
+                full = torch.empty(0, dtype=f.dtype, device=f.device).set_(st, f.storage_offset(), (need,) + tuple(f.shape[1:]))
+            else:
+                buf = torch.empty((need + int(self.SLACK * need) + 1024,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+                buf[:n_owned].copy_(f)
+                f, full = buf[:n_owned], buf[:need]
+            complete.append(full)
+            owned.append(f)
+        if nr:
+            tails = [c[n_owned:] for c in complete]
+            oarr, wid = self._table(tails)
+            self._chk(self.lib.sphx_dev_regroup(self.ctx.h, 0, None, nr, self._p(rows.contiguous()), len(fields), None, wid, oarr))
+        return complete, owned
 
     def need_map(self, pos, w, g_lo, g_cs, G):
         """uint8 (G^3,) map of the coarse cells a neighbour of an owned particle can lie in (one launch;
@@ -874,13 +905,20 @@ class DistributedSim:
             mean_h = self.hmean_prev
             # ---- halo phase 1: ghosts' state (88 B + previous h) ------------------------------
             loop = self.forms == "loop"
-            state_fields = [s["pos"], s["vel"], s["m"], s["T"], s["mu"], s["gam"], s["ptype"], s["h"]]
+            state_keys = ["pos", "vel", "m", "T", "mu", "gam", "ptype", "h"]
             if loop:
-                state_fields.append(s["E"])               # del_pressure reads the neighbour's E (nsc:755)
-            state_fields += [s[k_] for k_ in self.extra_fields]       # drag coefficients / composition rows of the ghosts
+                state_keys.append("E")                    # del_pressure reads the neighbour's E (nsc:755)
+            state_keys += list(self.extra_fields)         # drag coefficients / composition rows of the ghosts
+            state_fields = [s[k_] for k_ in state_keys]
             with self._sec("halo_state"):
                 g = self._exchange(send_idx, recv_counts, state_fields, send_cat=self.send_cat)
-                regrouped = self._regroup(None, no, g, state_fields)
+                if hasattr(be, "append_rows") and all(f.dtype == torch.float64 for f in state_fields):
+                    # the ghosts go behind the owned particles in the owned arrays' own storage: nothing else is copied
+                    regrouped, owned = be.append_rows(no, g, state_fields)
+                    for k_, v in zip(state_keys, owned):
+                        s[k_] = v
+                else:
+                    regrouped = self._regroup(None, no, g, state_fields)
                 pos, vel, m, T, mu, gam, ptype, hint = regrouped[:8]
                 E_all = regrouped[8] if loop else None
                 extra = dict(zip(self.extra_fields, regrouped[(9 if loop else 8):]))
