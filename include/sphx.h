@@ -374,6 +374,10 @@ int sphx_dev_loop_pass2(sphx_ctx* ctx, const double* rho_complete, double* visc_
  * split (LDS passes off: sphx_dev_loop_pass2 does everything), < 0 on error.  Results do not depend on the split.
  * sphx_dev_blob_split_counts: {interior, boundary, idle} blobs of the last search (a device-to-host read: diagnostics). */
 int sphx_dev_loop_pass2_interior(sphx_ctx* ctx);
+/* Head-room of the reach sphx_dev_reach / _reach_dt claim, limited to an absolute length `cap` (0: no limit):
+ * w_i = max(h_i + min((halo + skin - 1) h_i, cap), h_i + min((halo - 1) h_i, cap) + |v_i| dt).  The driver verifies
+ * every plan after the search and redoes the step if a radius outgrew its claim, so this only trades ghosts for redos. */
+int sphx_dev_set_reach_cap(sphx_ctx* ctx, double cap);
 /* The same overlap for hydro_update's sums.  sphx_dev_select_blobs(part): the calls of sphx_dev_prep / _density / _pi /
  * _visc that follow work on  1: the interior blobs (prep: the owned particles' records),  2: the boundary blobs (prep:
  * the ghosts' records),  0: everything (the default after every sphx_dev_search).  A pass is then called twice with the

@@ -106,6 +106,7 @@ SIGNATURES = {
     "sphx_dev_loop_pass1": (C.c_int, [_P] + [_P] * 5),
     "sphx_dev_loop_pass2": (C.c_int, [_P] + [_P] * 4),
     "sphx_dev_loop_pass2_interior": (C.c_int, [_P]),
+    "sphx_dev_set_reach_cap": (C.c_int, [_P, C.c_double]),
     "sphx_dev_select_blobs": (C.c_int, [_P, C.c_int]),
     "sphx_dev_blob_split_counts": (C.c_int, [_P, _P]),
     "sphx_dev_integrate_loop": (C.c_int, [_P, C.c_int64] + [_P] * 14 + [C.c_int, C.c_double, C.c_double, _P]),

@@ -801,15 +801,29 @@ extern "C" int sphx_dev_need_map(sphx_ctx* ctx, int64_t n, const double* pos, co
 // ---- small fused helpers of the decomposed driver (each replaces a dozen tensor-library launches) ------
 // reach claimed by every owned particle (DistributedSim._replan):
 //   w_i = max((halo + skin) h_i, halo h_i + |v_i| dt)
-__global__ __launch_bounds__(256) void reach_kernel(long long n, const double* h, const double* vel, double halo,
-                                                    double skin, double dt, double* w) {
+// or, with a cap c > 0 on the head-room (sphx_dev_set_reach_cap: an absolute length, a few mean radii - a particle whose
+// radius is many times the mean, the rim of an expanding cloud, then claims h_i + c instead of 1.3 h_i):
+//   w_i = max(h_i + min((halo + skin - 1) h_i, c), h_i + min((halo - 1) h_i, c) + |v_i| dt)
+__device__ __forceinline__ double reach_of(double hi, double speed, double dt, double halo, double skin, double cap) {
 #pragma clang fp contract(off)          // each operation rounded on its own, as the tensor-library form does
+    if (!(cap > 0.0)) return fmax((halo + skin) * hi, halo * hi + speed * dt);
+    const double a = fmin((halo + skin - 1.0) * hi, cap), b = fmin((halo - 1.0) * hi, cap);
+    return fmax(hi + a, (hi + b) + speed * dt);
+}
+__global__ __launch_bounds__(256) void reach_kernel(long long n, const double* h, const double* vel, double halo,
+                                                    double skin, double dt, double cap, double* w) {
+#pragma clang fp contract(off)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
     const double speed = sqrt((vx * vx + vy * vy) + vz * vz);
     const double hi = h[i];
-    w[i] = fmax((halo + skin) * hi, halo * hi + speed * dt);
+    w[i] = reach_of(hi, speed, dt, halo, skin, cap);
+}
+extern "C" int sphx_dev_set_reach_cap(sphx_ctx* ctx, double cap) {
+    if (!ctx) return SPHX_E_ARG;
+    ctx->reach_cap = cap > 0.0 ? cap : 0.0;
+    return SPHX_OK;
 }
 extern "C" int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
                               double skin_frac, double dt_last, double* w) {
@@ -819,7 +833,7 @@ extern "C" int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const d
     NEED(h); NEED(vel); NEED(w);
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(reach_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, h, vel,
-                       halo_scale, skin_frac, dt_last, w);
+                       halo_scale, skin_frac, dt_last, ctx->reach_cap, w);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -827,7 +841,7 @@ extern "C" int sphx_dev_reach(sphx_ctx* ctx, int64_t n, const double* h, const d
 // the same with dt read from device memory (the step's dt as sphx_dev_integrate_auto left it): the next step's plan is
 // made before the host has seen this step's scalars
 __global__ __launch_bounds__(256) void reach_dt_kernel(long long n, const double* h, const double* vel, double halo,
-                                                       double skin, const double* dt_dev, double* w) {
+                                                       double skin, const double* dt_dev, double cap, double* w) {
 #pragma clang fp contract(off)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -835,7 +849,7 @@ __global__ __launch_bounds__(256) void reach_dt_kernel(long long n, const double
     const double vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
     const double speed = sqrt((vx * vx + vy * vy) + vz * vz);
     const double hi = h[i];
-    w[i] = fmax((halo + skin) * hi, halo * hi + speed * dt);
+    w[i] = reach_of(hi, speed, dt, halo, skin, cap);
 }
 extern "C" int sphx_dev_reach_dt(sphx_ctx* ctx, int64_t n, const double* h, const double* vel, double halo_scale,
                                  double skin_frac, const double* dt_dev, double* w) {
@@ -845,7 +859,7 @@ extern "C" int sphx_dev_reach_dt(sphx_ctx* ctx, int64_t n, const double* h, cons
     NEED(h); NEED(vel); NEED(w); NEED(dt_dev);
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(reach_dt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, h, vel,
-                       halo_scale, skin_frac, dt_dev, w);
+                       halo_scale, skin_frac, dt_dev, ctx->reach_cap, w);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

@@ -263,6 +263,9 @@ class LibBackend:
                                              self._p(w.contiguous()), lo, float(g_cs), int(G), self._p(out)))
         return out
 
+    def set_reach_cap(self, cap_abs):
+        self._chk(self.lib.sphx_dev_set_reach_cap(self.ctx.h, float(cap_abs)))
+
     def reach(self, h, vel, halo_scale, skin_frac, dt_last):
         """w_i = max((halo + skin) h_i, halo h_i + |v_i| dt) in one launch (sphx_dev_reach)."""
         w = torch.empty_like(h)
@@ -542,6 +545,10 @@ class DistributedSim:
         # how much of |v_i| dt a particle adds to the reach it claims (1: a radius may grow by the particle's own displacement
         # per step; every plan is verified after the search and redone if too thin, so this only trades ghosts for redos)
         self.reach_vfac = float(os.environ.get("SPHX_REACH_VFAC", "1.0"))
+        # head-room of a claim limited to this many MEAN radii (0: not): the rim of an expanding cloud (radii tens of times
+        # the mean, growing by a fraction of a per cent per step) otherwise claims 30 % of its own radius into the dense core
+        self.reach_cap = float(os.environ.get("SPHX_REACH_CAP", "1.0"))
+        self.cap_abs = 0.0                # the cap as a length: set when particles migrate (the same for every plan in between)
         self.overlap = os.environ.get("SPHX_MG_OVERLAP", "1") != "0"      # interior blobs' sums under the scalar halo phases
         self.plan_next = None             # the NEXT step's plan, made at the end of this one (see step)
         self.plan_ahead = True
@@ -783,6 +790,9 @@ class DistributedSim:
         claims the radius w_i = (halo_scale + skin_frac) * grow * h_i around itself."""
         if self._migration_due():
             self._reorder_and_migrate()
+            self.cap_abs = self.reach_cap * self.hmean_prev if self.hmean_prev > 0.0 else 0.0
+            if hasattr(self.backend, "set_reach_cap"):
+                self.backend.set_reach_cap(self.cap_abs)
         s = self.s
         # reach claimed by each owned particle: its kNN radius with head-room for one step of growth
         # (a radius changes by at most twice the local displacement, so fast movers claim more)
@@ -790,8 +800,14 @@ class DistributedSim:
             self.w_plan = self.backend.reach(s["h"], s["vel"], self.halo_scale, self.skin_frac, self.dt_last * self.reach_vfac)
         else:
             speed = torch.sqrt((s["vel"] * s["vel"]).sum(dim=1))
-            self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"],
-                                        self.halo_scale * s["h"] + speed * (self.dt_last * self.reach_vfac))
+            dtv = self.dt_last * self.reach_vfac
+            if self.cap_abs > 0.0:
+                cap = torch.full_like(s["h"], self.cap_abs)
+                a = torch.minimum((self.halo_scale + self.skin_frac - 1.0) * s["h"], cap)
+                b = torch.minimum((self.halo_scale - 1.0) * s["h"], cap)
+                self.w_plan = torch.maximum(s["h"] + a, (s["h"] + b) + speed * dtv)
+            else:
+                self.w_plan = torch.maximum((self.halo_scale + self.skin_frac) * s["h"], self.halo_scale * s["h"] + speed * dtv)
         if self.world > 1:
             self.send_idx, self.recv_counts = self._plan(self.w_plan)
         else:
@@ -886,7 +902,10 @@ class DistributedSim:
                 else:
                     d_loc = 0.0
                 D = self._allreduce_max(d_loc)                    # bound on the displacement norm
-                stale = float((self.halo_scale * s["h"] + 2.0 * D > self.w_plan).any()) if no else 0.0
+                hr = (self.halo_scale - 1.0) * s["h"]              # (the head-room a plan is expected to keep)
+                if self.cap_abs > 0.0:
+                    hr = torch.clamp(hr, max=self.cap_abs)
+                stale = float((s["h"] + hr + 2.0 * D > self.w_plan).any()) if no else 0.0
                 is_stale = self._allreduce_max(stale) > 0.5       # (the same verdict on every rank)
             if is_stale:
                 with self._sec("replan"):

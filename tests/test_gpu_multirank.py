@@ -403,6 +403,18 @@ def test_fused_reach_and_step_scalars_match_tensor_forms():
     speed = torch.sqrt((vel * vel).sum(dim=1))
     w_ref = torch.maximum((halo + skin) * h, halo * h + speed * dt)
     assert float(((w - w_ref).abs() / w_ref).max()) <= 4e-16      # (the same expression, to rounding)
+    # head-room capped at an absolute length (sphx_dev_set_reach_cap): the escaper claims h + cap (+ its displacement)
+    cap = 0.2
+    be.set_reach_cap(cap)
+    wc = be.reach(h, vel, halo, skin, dt)
+    dt_dev = torch.tensor([dt], dtype=torch.float64, device=dev)
+    wc_dt = be.reach_dt(h, vel, halo, skin, dt_dev)
+    be.set_reach_cap(0.0)
+    capt = torch.full_like(h, cap)
+    wc_ref = torch.maximum(h + torch.minimum((halo + skin - 1.0) * h, capt), (h + torch.minimum((halo - 1.0) * h, capt)) + speed * dt)
+    assert float(((wc - wc_ref).abs() / wc_ref).max()) <= 4e-16 and torch.equal(wc_dt, wc)
+    assert float(wc[17]) <= 40.0 + cap + float(speed[17]) * dt + 1e-9 and float(w[17]) >= 52.0 - 1e-9
+    assert bool((wc <= w * (1 + 1e-15)).all()) and bool((wc >= h).all())
     ct = torch.tensor([3.25], dtype=torch.float64, device=dev)
     for D, hmean_prev in ((0.0, 1.0), (0.02, 1.0), (0.4, 0.0)):
         hclip = 8.0 * hmean_prev if hmean_prev > 0 else 0.0
