@@ -491,6 +491,8 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     if (cell < Lmax * 1e-4) cell = Lmax * 1e-4;
     int64_t cap = 32 * n + 1024;      // cells per particle the grid may use when a diffuse halo stretches the box
     if (cap > SPHX_MAX_CELLS) cap = SPHX_MAX_CELLS;
+    if (ctx->max_cells > 0 && cap > ctx->max_cells) cap = ctx->max_cells;
+    if (ctx->max_cells < 0) { cap = 32 * n + 1024; if (cap > -ctx->max_cells) cap = -ctx->max_cells; }   // experiment: beyond the default limit
     int nx, ny, nz;
     for (;;) {
         nx = (int)fmin(floor(L[0] / cell) + 1.0, 2047.0);

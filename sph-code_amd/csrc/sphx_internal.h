@@ -247,6 +247,7 @@ struct sphx_ctx {
     //  by side, both HBM-bound: the pair takes the 182 us it takes back to back.  SPHX_DEV_FORK_DEDUP=1 to try it where
     //  the main stream would otherwise wait for the network between the search and the first pass)
     bool dev_fork_dedup = false;
+    int64_t max_cells = 0;          // SPHX_MAX_CELLS: > 0 lowers the limit on grid cells, < 0 (experiment) raises it to |value|
     double reach_cap = 0.0;         // sphx_dev_set_reach_cap: head-room of a claimed reach limited to this length (0: not)
     int pass_part = 0;              // which blobs hydro_update's passes and the record build take: 0 all, 1 interior, 2 boundary
     bool blob_attr_set = false;

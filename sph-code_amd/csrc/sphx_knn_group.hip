@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     // a usable hint: finite, positive, not beyond the caller's bound (bounded searches take the general kernel)
     bool ok = is_query && R > 0.0 && R < 1e300 && R < a.rbound && isfinite(qx) && isfinite(qy) && isfinite(qz);
     bool fail = is_query && !ok;
+    // one wide radius among 64 (a rim particle among surface particles) would size the tile for all of them and push the
+    // whole group over its caps: a query KG_RSPREAD times above the group's smallest radius goes to the general kernel alone
+    {
+        const double Rmin = wmin(ok ? R : (double)INFINITY);
+        if (ok && R > KG_RSPREAD * Rmin) { ok = false; fail = true; }
+    }
     int why = fail ? 1 : 0;                     // diagnostics: 1 no hint, 2 tile, 3 tolerance, 4 > 64 inside, 5 < K inside, 6 near tie
     const u64 okmask = __builtin_amdgcn_ballot_w64(ok);
     if (wave == 0) {
