@@ -6,7 +6,7 @@
 #define KG_TCAP 1408                     // candidates per group tile after the cull (11 bits of a key name the slot)
 #endif
 #ifndef KG_RSPREAD
-#define KG_RSPREAD 2.0                   // widest radius a group's tile is sized for, in units of the group's smallest
+#define KG_RSPREAD 1.5                   // widest radius a group's tile is sized for, in units of the group's smallest
 #endif
 #define KG_TPRE 3072                     // candidates of the rows of cells before the per-candidate cull (row ids: u16)
 #define KG_MAXROWS 512                   // NON-EMPTY rows of cells a group's tile may draw from
