@@ -752,11 +752,16 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.short_rows = (int64_t)sc[SC_SHORT];
     if (getenv("SPHX_KNN_PROF")) {
         const char* nm[4] = {"in-box", "-", "outside the box", "-"};
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; c += 2)          // (the odd slots: cycles by section of the same two classes, below)
             if (sc[SC_KNNPROF + 4 + c])
                 fprintf(stderr, "[sphx] general search, %-17s: %9llu queries, %8.0f cycles each, longest %10llu, %.2f tries each\n", nm[c],
                         sc[SC_KNNPROF + 4 + c], (double)sc[SC_KNNPROF + c] / (double)sc[SC_KNNPROF + 4 + c], sc[SC_KNNPROF + 8 + c],
                         (double)sc[SC_KNNPROF + 12 + c] / (double)sc[SC_KNNPROF + 4 + c]);
+        for (int c = 0; c < 4; c += 2)
+            if (sc[SC_KNNPROF + 4 + c])
+                fprintf(stderr, "[sphx]   %-17s per query: %.1f batches of rows; cycles in row set-up %.0f, candidates %.0f, ranking %.0f\n", nm[c],
+                        (double)sc[SC_KNNPROF + 13 + c] / (double)sc[SC_KNNPROF + 4 + c], (double)sc[SC_KNNPROF + 1 + c] / (double)sc[SC_KNNPROF + 4 + c],
+                        (double)sc[SC_KNNPROF + 5 + c] / (double)sc[SC_KNNPROF + 4 + c], (double)sc[SC_KNNPROF + 9 + c] / (double)sc[SC_KNNPROF + 4 + c]);
         const double* dbg = (const double*)(sc + SC_KNNPROF + 16);
         if (dbg[7] > 0.0)
             fprintf(stderr, "[sphx]   a long one: at (%.4g %.4g %.4g), radius given %.4g, found h %.4g, %g retries, %g candidates, %g cycles | box origin (%.4g %.4g %.4g) cell %.4g dims %d %d %d\n",

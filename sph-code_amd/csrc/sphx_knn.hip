@@ -188,6 +188,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
     u64 ncand = 0, nretry = 0, nshort = 0, nfar = 0, nbad = 0;
 #ifdef SPHX_KNN_PROF
     u64 p_sum[2] = {0, 0}, p_n[2] = {0, 0}, p_max[2] = {0, 0}, p_tries[2] = {0, 0};
+    u64 p_sec[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // row set-up, candidates, ranking (cycles); batches of rows
 #endif
 
     do {
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
         const long long prof_t0 = clock64();
         const u64 prof_c0 = ncand;
         int prof_cat = q_out ? 3 : 0;
+        u64 q_sec[4] = {0, 0, 0, 0};
 #endif
         // A stale hint: the particle has moved (a diverging run moves it by several h per step) into a neighbourhood far
         // denser than its previous radius implies - the 3x3x3 block of cells around it alone holds many times what a sphere
@@ -372,6 +374,10 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             float Rc2 = Rc * Rc;             // shrinks with the running K-th best (rows and chords still to come are clipped to it)
 
             for (int rb = 0; rb < (ABL == 3 ? 0 : nrows); rb += 64) {
+#ifdef SPHX_KNN_PROF
+                const long long ts0 = clock64();
+                u64 d_iter = 0;
+#endif
                 // ---- one lane per (cy,cz) row of cells: clip the row to the search SPHERE ----
                 const int r = rb + lane;
                 int s_row = 0, cnt = 0;
@@ -406,6 +412,10 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                 const int sb = s_row - (incl - cnt);      // candidate slot t of row r is particle sb[r] + t
                 const int T = __builtin_amdgcn_readlane(incl, 63);
                 ncand += (u64)T;
+#ifdef SPHX_KNN_PROF
+                const long long ts1 = clock64();
+                q_sec[0] += (u64)(ts1 - ts0); q_sec[3] += 1;
+#endif
 
                 const int off = incl - cnt;
                 // Slot -> particle map.  Non-empty rows are compacted (rbase[ordinal] = sb) and each
@@ -497,6 +507,9 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                         }
                         nst += c;
                         if (nst >= 64) {
+#ifdef SPHX_KNN_PROF
+                            const long long td0 = clock64();
+#endif
                             wave_sync();
                             u64 ck; u32 cv;
                             sort_staged<ABL>(skey, sid, head, 64, R2, lane, ck, cv);
@@ -520,6 +533,9 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                                 const float rk = (float)(sqrt(__longlong_as_double((long long)kth)) * icell) * 1.00001f + 2e-3f;
                                 Rc2 = fminf(Rc2, rk * rk);
                             }
+#ifdef SPHX_KNN_PROF
+                            d_iter += (u64)(clock64() - td0);
+#endif
                         }
                     }
                 }
@@ -528,6 +544,9 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                     if (ne) rflag[off] = 0;
                     wave_sync();
                 }
+#ifdef SPHX_KNN_PROF
+                q_sec[1] += (u64)(clock64() - ts1) - d_iter; q_sec[2] += d_iter;
+#endif
             }
             if (!OUTL || !multi || lv == 0) break;
             // between structures: rank what is staged; with K candidates in hand nothing beyond the K-th can matter
@@ -622,6 +641,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             const u64 dtc = (u64)(clock64() - prof_t0);
             const int pc = prof_cat >= 2 ? 1 : 0;
             p_sum[pc] += dtc; p_n[pc] += 1; p_tries[pc] += (u64)(tries + 1);
+            for (int q = 0; q < 4; ++q) p_sec[pc][q] += q_sec[q];
             if (dtc > p_max[pc]) p_max[pc] = dtc;
             if (dtc > SPHX_KNN_PROF_LONG && lane == 0 && a.counters) {        // a monster: who is it?
                 double* dbg = (double*)(a.counters + SC_KNNPROF + 16);
@@ -682,6 +702,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                 atomicAdd(&a.counters[SC_KNNPROF + 4 + 2 * pc], p_n[pc]);
                 atomicMax(&a.counters[SC_KNNPROF + 8 + 2 * pc], p_max[pc]);
                 atomicAdd(&a.counters[SC_KNNPROF + 12 + 2 * pc], p_tries[pc]);
+                for (int q = 0; q < 4; ++q) atomicAdd(&a.counters[SC_KNNPROF + 4 * q + 2 * pc + 1], p_sec[pc][q]);
             }
 #endif
     }
