@@ -159,6 +159,33 @@ def test_ranks_sharing_one_gpu_match_oracle(world, workload, tmp_path):
     assert sum(p["stats"][0] for p in parts) > 0
 
 
+@pytest.mark.parametrize("forms,workload", [("hydro_update", "polytrope"), ("loop", "uniform_cube")])
+def test_two_ranks_match_the_fused_step_at_2e5_particles(forms, workload, tmp_path):
+    """The decomposed step at a size where a rank has a thousand workgroups of both kinds (interior ones under the halo
+    phases, boundary ones after), ghosts appended in place behind 10^5 owned particles, plans made ahead: against the
+    single-GPU fused loop on the same state (itself pinned to the oracle at small sizes and to the array API at 10^6)."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, nsteps, world = 200000, 4, 2
+    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, workload, str(tmp_path), forms), nprocs=world, join=True)
+    parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    assert all(p["blob_split"][0] > 100 and p["blob_split"][1] > 20 for p in parts)
+    order = np.argsort(np.concatenate([p["gid"] for p in parts]))
+    got = {k_: np.concatenate([p[k_] for p in parts])[order]
+           for k_ in ("points", "velocities", "total_accel", "E_internal", "sizes", "densities")}
+    state = ics.WORKLOADS[workload](n, light=True)
+    kw = dict(forms="loop", d=ics.loop_d(state, K)) if forms == "loop" else {}
+    sim = Simulation(state, n_neigh=K, **kw)
+    sim.step(nsteps)
+    ref = sim.download()
+    assert float(parts[0]["dt"]) == pytest.approx(ref["dt"], rel=1e-13)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-13)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
+    np.testing.assert_allclose(got["E_internal"], ref["E_internal"], rtol=1e-11)
+    for k_ in ("points", "velocities", "total_accel"):
+        assert np.max(np.abs(got[k_] - ref[k_])) <= 1e-10 * np.max(np.abs(ref[k_])), k_
+
+
 def test_two_ranks_redone_steps_match_oracle(tmp_path, monkeypatch):
     """Plans with no head-room (claimed reach = the previous radius itself, no skin, no velocity term): the post-search verdict finds them too thin, the failing
     particles claim more, everybody replans - migrating by the order of the attempt just made when a migration is due -
