@@ -88,6 +88,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
     if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_MAX_CELLS")) ctx->max_cells = atoll(e);
+    if (const char* e = getenv("SPHX_DRAG_LDS")) ctx->drag_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
     if (const char* e = getenv("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
@@ -158,7 +159,8 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->in_g, &ctx->in_h, &ctx->in_i,
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
-                     &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust};
+                     &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
+                     &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);

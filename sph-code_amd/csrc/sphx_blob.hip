@@ -748,6 +748,155 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
 
 // ---- launchers (buffers are sized by the callers in sphx_sums.hip) -----------------------------
 // persistent grid: two workgroups per CU (what the LDS image allows), a multiple of the 8 XCDs
+// ---- gas-dust drag out of LDS                 nsc:719-742 (net_impulse; gather form: sphx_sums.hip) ---------------------
+// Only dust neighbours count (a tenth of the references in the two-phase cloud), and every one of them costs the
+// gather form a chain of gathers (type, record, m, grain mass, cross-section) and an atomic with return for its place
+// in the receiver's slice of the ordered scatter.  Here the blob's distinct neighbours carry a dust flag in LDS, the
+// references to each are counted in LDS, and the blob reserves its share of a receiver's slice with ONE global atomic
+// per distinct dust neighbour (ranks inside the share come from an LDS counter; the order within a slice is free: the
+// reduction sorts by key).  FILL = false: the counting pass of the scatter plan (sphx_drag_scatter_plan).
+#define DRAG_XLDS (BLOB_S * (2 * sizeof(int) + 1))          // count, base, dust flag per image slot
+template <bool FILL>
+__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_drag_kernel(int n, int npad, int k, int nblk,
+                                                           const int* __restrict__ nbr,
+                                                           const u16* __restrict__ slot16,
+                                                           const int* __restrict__ uniq,
+                                                           const int* __restrict__ qorder,
+                                                           const RecB* __restrict__ recb,
+                                                           const double* __restrict__ m,
+                                                           const double* __restrict__ ptype,
+                                                           const double* __restrict__ mgm,
+                                                           const double* __restrict__ mcs,
+                                                           const int* __restrict__ id, double* onto, DragScatter sc) {
+    extern __shared__ double2 img[];                       // FILL: 4 * BLOB_S chunks; then the slot tile, counts, bases, flags
+    u16* tile = reinterpret_cast<u16*>(img + (FILL ? 4 * BLOB_S : 0));
+    int* cntL = reinterpret_cast<int*>(tile + KPAD(k) * BLOB_P);
+    int* baseL = cntL + BLOB_S;
+    unsigned char* dust = reinterpret_cast<unsigned char*>(baseL + BLOB_S);
+    const int t = threadIdx.x / LPP, part = threadIdx.x & (LPP - 1);
+    const int nm = KPAD(k) / LPP;
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const bool live = p < n;
+        const int i = live ? qorder[p] : 0;
+        const int* uq = uniq + (size_t)b * BLOB_S;
+        if (FILL) {
+            stage<0>(img, nullptr, tile, recb, nullptr, 0, nullptr, 0, uq, slot16, npad, k, b);
+        } else {
+            const int pieces = KPAD(k) * (BLOB_P / 8);
+            for (int q = threadIdx.x; q < pieces; q += PASS_T) {
+                const int kk = q / (BLOB_P / 8), c = q % (BLOB_P / 8);
+                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (kk < k) v = *reinterpret_cast<const uint4*>(slot16 + (size_t)kk * npad + (size_t)b * BLOB_P + c * 8);
+                *reinterpret_cast<uint4*>(tile + kk * BLOB_P + c * 8) = v;
+            }
+        }
+        for (int s = threadIdx.x; s < BLOB_S; s += PASS_T) {
+            const int j = uq[s];
+            dust[s] = (j >= 0 && ptype[j] == 2.0) ? 1 : 0;                       // nsc:736
+            cntL[s] = 0;
+        }
+        __syncthreads();
+        // references per distinct dust neighbour (a particle's reference to itself casts no reaction: nsc:741)
+        if (live) {
+            for (int m0 = 0; m0 < nm; ++m0) {
+                const int kk = LPP * m0 + part;
+                const unsigned sl = tile[kk * BLOB_P + t];
+                if (sl < SLOT_OVER) {
+                    if (dust[sl] && uq[sl] != i) atomicAdd(&cntL[sl], 1);
+                } else if (sl == SLOT_OVER && !FILL) {
+                    const int j = nbr[(size_t)kk * npad + p];
+                    if (j != i && ptype[j] == 2.0) atomicAdd(&sc.cnt[j], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (!FILL) {
+            for (int s = threadIdx.x; s < BLOB_S; s += PASS_T)
+                if (cntL[s]) atomicAdd(&sc.cnt[uq[s]], cntL[s]);
+            __syncthreads();
+            continue;
+        }
+        // the blob's share of every receiver's slice (handed out from the slice's end, as the gather form does)
+        for (int s = threadIdx.x; s < BLOB_S; s += PASS_T) {
+            const int c = cntL[s];
+            if (c) {
+                const int j = uq[s];
+                baseL[s] = sc.start[j] + atomicSub(&sc.cnt[j], c) - c;
+                cntL[s] = 0;
+            }
+        }
+        const double* rq = reinterpret_cast<const double*>(&recb[i]);
+        const Q4 r0 = gload4(rq), rv = gload4(rq + 4);
+        __syncthreads();
+        double ox = 0.0, oy = 0.0, oz = 0.0;
+        if (live) {
+            for (int m0 = 0; m0 < nm; ++m0) {
+                const int kk = LPP * m0 + part;
+                const unsigned sl = tile[kk * BLOB_P + t];
+                int j;
+                Q4 q0, qv;
+                if (sl < SLOT_OVER) {
+                    if (!dust[sl]) continue;
+                    j = uq[sl];
+                    q0 = lload4(img, (int)sl, 0); qv = lload4(img, (int)sl, 1);
+                } else if (sl == SLOT_OVER) {
+                    j = nbr[(size_t)kk * npad + p];
+                    if (ptype[j] != 2.0) continue;
+                    const double* qb = reinterpret_cast<const double*>(&recb[j]);
+                    q0 = gload4(qb); qv = gload4(qb + 4);
+                } else {
+                    continue;
+                }
+                const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
+                const double ds2 = q0.d, ds = sqrt(ds2);
+                const double q = ds2 - (dx * dx + dy * dy + dz * dz);
+                const double ds4 = ds2 * ds2;
+                const double wf = m[j] * 315.0 * (q * q * q) / (201.06192982974676 * (ds4 * ds4 * ds));   // nsc:678-681
+                double fx = 0.0, fy = 0.0, fz = 0.0;
+                if (wf > 0.0) {
+                    const double dvx = qv.a - rv.a, dvy = qv.b - rv.b, dvz = qv.c - rv.c;
+                    const double coef = wf / mgm[j] * mcs[j] * sqrt(dvx * dvx + dvy * dvy + dvz * dvz);
+                    fx = coef * dvx; fy = coef * dvy; fz = coef * dvz;
+                    ox += fx; oy += fy; oz += fz;
+                }
+                if (j != i) {                                              // nsc:741
+                    const int slot = (sl < SLOT_OVER) ? baseL[sl] + atomicAdd(&cntL[sl], 1)
+                                                      : sc.start[j] + atomicSub(&sc.cnt[j], 1) - 1;
+                    sphx_drag_put(sc, slot, ((u64)(unsigned)id[i] << 8) | (u64)kk, -fx, -fy, -fz);
+                }
+            }
+        }
+        const double tx = group_total(ox), ty = group_total(oy), tz = group_total(oz);
+        if (live && part == 0) { onto[3 * (size_t)i] = tx; onto[3 * (size_t)i + 1] = ty; onto[3 * (size_t)i + 2] = tz; }
+        __syncthreads();
+    }
+}
+
+// counting pass of the scatter plan (true) / the pass itself (false -> fill) on the blob lists
+int sphx_blob_drag(sphx_ctx* ctx, int64_t n, int k, bool count_only, const double* m, const double* ptype, const double* mgm,
+                   const double* mcs, const int* id, double* onto, const DragScatter& sc) {
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    if (!ctx->drag_attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_drag_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(IMG_BYTES(64, SPHX_MAX_K) + DRAG_XLDS)));
+        ctx->drag_attr_set = true;
+    }
+    if (count_only)
+        hipLaunchKernelGGL(blob_drag_kernel<false>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T),
+                           (size_t)KPAD(k) * BLOB_P * sizeof(u16) + DRAG_XLDS, ctx->stream, (int)n, (int)npad, k, nblk,
+                           ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, nullptr, m, ptype, mgm, mcs,
+                           id, onto, sc);
+    else
+        hipLaunchKernelGGL(blob_drag_kernel<true>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k) + DRAG_XLDS,
+                           ctx->stream, (int)n, (int)npad, k, nblk, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
+                           ctx->qorder, ctx->recv.as<RecB>(), m, ptype, mgm, mcs, id, onto, sc);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
 int sphx_blob_join(sphx_ctx* ctx) {
     if (ctx->dedup_pending) {
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

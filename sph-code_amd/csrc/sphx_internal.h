@@ -154,7 +154,7 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     DevBuf need_pyr;              // sphx_dev_need_map: widest claim per coarse cell + the pyramid of maxima over it
-    DevBuf ds_cnt, ds_start, ds_keys, ds_vals;   // ordered scatter of the reaction (DragScatter)
+    DevBuf ds_cnt, ds_start, ds_ent;             // ordered scatter of the reaction (DragScatter)
     const void* ds_cnt_zeroed = nullptr;
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)
     bool dev_ev_pending = false;  // sphx_dev_search recorded ev[1]/ev[2] around its kNN launch: not yet read
@@ -242,6 +242,7 @@ struct sphx_ctx {
     bool blob_split_on = true, blob_split_valid = false;
     int blob_split_nblk = 0;
     bool loop2_interior_done = false;
+    bool drag_attr_set = false, drag_lds = true;
     bool dedup_pending = false;     // device API: the dedup of the last search runs on the side stream (joined by sphx_blob_join)
     // (off: measured at one rank, 10^6 particles - dedup 109 -> 169 us and the record build 73 -> 95 us when they run side
     //  by side, both HBM-bound: the pair takes the 182 us it takes back to back.  SPHX_DEV_FORK_DEDUP=1 to try it where
@@ -399,9 +400,21 @@ int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n);   // out[
 // contributions to a particle are first laid side by side (slices from a count + scan), then added in the order the
 // reference's np.add.at adds them - by source particle (caller index), then list position - so the sum is the same bits on
 // every run, and the reference's.  sphx_drag_scatter_plan: count + scan; the drag kernels fill; sphx_drag_scatter_reduce adds.
-struct DragScatter { int* cnt; const int* start; u64* keys; double* vals; };
-int sphx_drag_scatter_plan(sphx_ctx* ctx, int64_t n, int k, const int* nbr, const double* ptype, const int* qorder, DragScatter* out);
+// (an entry is one aligned 32-byte record - key and the three components leave in one piece: written as four scattered
+//  8-byte stores, the fill cost four memory sectors per reference)
+struct alignas(32) DragEntry { u64 key; double x, y, z; };
+struct DragScatter { int* cnt; const int* start; DragEntry* ent; };
+__device__ __forceinline__ void sphx_drag_put(const DragScatter& sc, int slot, u64 key, double x, double y, double z) {
+    double2* q = reinterpret_cast<double2*>(sc.ent + slot);
+    q[0] = make_double2(__longlong_as_double((long long)key), x);
+    q[1] = make_double2(y, z);
+}
+int sphx_drag_scatter_plan(sphx_ctx* ctx, int64_t n, int k, const int* nbr, const double* ptype, const int* qorder, DragScatter* out,
+                           bool blob = false);
 int sphx_drag_scatter_reduce(sphx_ctx* ctx, int64_t n, const DragScatter& d, double* react);
+// the step's drag pass on the blob lists (sphx_blob.hip): count_only = the counting pass of the scatter plan
+int sphx_blob_drag(sphx_ctx* ctx, int64_t n, int k, bool count_only, const double* m, const double* ptype, const double* mgm,
+                   const double* mcs, const int* id, double* onto, const DragScatter& sc);
 int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const double* ys, const double* zs);   // (sorted order)
 // knn
 struct KnnOut {

@@ -187,8 +187,7 @@ __global__ __launch_bounds__(256) void loop_impulse_kernel(LoopArgs a, DragScatt
         }
         if (j != i) {
             const int slot = sc.start[j] + atomicSub(&sc.cnt[j], 1) - 1;
-            sc.keys[slot] = ((u64)(unsigned)i << 12) | (u64)kk;
-            sc.vals[3 * (size_t)slot] = -fx; sc.vals[3 * (size_t)slot + 1] = -fy; sc.vals[3 * (size_t)slot + 2] = -fz;
+            sphx_drag_put(sc, slot, ((u64)(unsigned)i << 12) | (u64)kk, -fx, -fy, -fz);
         }
     }
     a.out3[3 * (size_t)i] = ox; a.out3[3 * (size_t)i + 1] = oy; a.out3[3 * (size_t)i + 2] = oz;

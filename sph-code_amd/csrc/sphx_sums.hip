@@ -424,14 +424,20 @@ __global__ __launch_bounds__(256) void drag_count_kernel(int n, int npad, int k,
 #define DRAG_RED_U 4                      // entries per lane the wave form holds: slices up to 256 entries
 // the slice [s, s + L) added in key order -> (ax, ay, az), valid in lane 0
 template <int U>
-__device__ __forceinline__ void drag_slice_sum(int s, int L, const u64* __restrict__ keys, const double* __restrict__ vals,
+__device__ __forceinline__ void drag_slice_sum(int s, int L, const DragEntry* __restrict__ ent,
                                                double* pk, int lane, double& ax, double& ay, double& az) {
     u64 key[U];
+    double vx[U], vy[U], vz[U];
     int rank[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int q = lane + 64 * u;
-        key[u] = q < L ? keys[s + q] : ~0ull;
+        key[u] = ~0ull; vx[u] = vy[u] = vz[u] = 0.0;
+        if (q < L) {
+            const double2* e = reinterpret_cast<const double2*>(ent + s + q);
+            const double2 e0 = e[0], e1 = e[1];
+            key[u] = (u64)__double_as_longlong(e0.x); vx[u] = e0.y; vy[u] = e1.x; vz[u] = e1.y;
+        }
         rank[u] = 0;
     }
 #pragma unroll
@@ -447,10 +453,7 @@ __device__ __forceinline__ void drag_slice_sum(int s, int L, const u64* __restri
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int q = lane + 64 * u;
-        if (q < L) {
-            const double* v = vals + 3 * (size_t)(s + q);
-            pk[3 * rank[u]] = v[0]; pk[3 * rank[u] + 1] = v[1]; pk[3 * rank[u] + 2] = v[2];
-        }
+        if (q < L) { pk[3 * rank[u]] = vx[u]; pk[3 * rank[u] + 1] = vy[u]; pk[3 * rank[u] + 2] = vz[u]; }
     }
     wave_sync();
     if (lane == 0)
@@ -459,8 +462,8 @@ __device__ __forceinline__ void drag_slice_sum(int s, int L, const u64* __restri
 }
 // A wave takes 64 consecutive receivers at a time: every lane looks up one slice (most are empty: zeros written at once),
 // the non-empty ones are then added one after the other by the whole wave.
-__global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __restrict__ start, const u64* __restrict__ keys,
-                                                          const double* __restrict__ vals, double* react) {
+__global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __restrict__ start,
+                                                          const DragEntry* __restrict__ ent, double* react) {
     __shared__ double parked[4][64 * DRAG_RED_U * 3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* pk = parked[wave];
@@ -477,9 +480,9 @@ __global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __re
             const int j = j0 + t;
             double ax = 0.0, ay = 0.0, az = 0.0;
             if (L <= 64) {
-                drag_slice_sum<1>(s, L, keys, vals, pk, lane, ax, ay, az);
+                drag_slice_sum<1>(s, L, ent, pk, lane, ax, ay, az);
             } else if (L <= 64 * DRAG_RED_U) {
-                drag_slice_sum<DRAG_RED_U>(s, L, keys, vals, pk, lane, ax, ay, az);
+                drag_slice_sum<DRAG_RED_U>(s, L, ent, pk, lane, ax, ay, az);
             } else if (lane == 0) {                       // a very long slice: smallest remaining key first, one lane
                 u64 last = 0;
                 bool have = false;
@@ -487,10 +490,10 @@ __global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __re
                     u64 best = ~0ull;
                     int bi = -1;
                     for (int q = s; q < s + L; ++q) {
-                        const u64 kq = keys[q];
+                        const u64 kq = ent[q].key;
                         if ((!have || kq > last) && kq < best) { best = kq; bi = q; }
                     }
-                    ax += vals[3 * (size_t)bi]; ay += vals[3 * (size_t)bi + 1]; az += vals[3 * (size_t)bi + 2];
+                    ax += ent[bi].x; ay += ent[bi].y; az += ent[bi].z;
                     last = best;
                     have = true;
                 }
@@ -500,29 +503,32 @@ __global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __re
     }
 }
 int sphx_drag_scatter_plan(sphx_ctx* ctx, int64_t n, int k, const int* nbr, const double* ptype, const int* qorder,
-                           DragScatter* out) {
+                           DragScatter* out, bool blob) {
     const size_t cap0 = ctx->ds_cnt.cap;
     SPHX_TRY(sphx_ensure(ctx, ctx->ds_cnt, ((size_t)n + 2) * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ds_start, ((size_t)n + 2) * sizeof(int)));
     // (every reference could be to a dust particle: n k entries; memory is what this machine has)
-    SPHX_TRY(sphx_ensure(ctx, ctx->ds_keys, (size_t)n * k * sizeof(u64)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->ds_vals, (size_t)n * k * 3 * sizeof(double)));
+    SPHX_TRY(sphx_ensure(ctx, ctx->ds_ent, (size_t)n * k * sizeof(DragEntry)));
     if (ctx->ds_cnt.cap != cap0 || ctx->ds_cnt_zeroed != ctx->ds_cnt.p) {     // counted up here, back down by the fill
         HIPCHK(hipMemsetAsync(ctx->ds_cnt.p, 0, ctx->ds_cnt.cap, ctx->stream));
         ctx->ds_cnt_zeroed = ctx->ds_cnt.p;
     }
-    hipLaunchKernelGGL(drag_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       (int)sphx_pad64(n), k, nbr, ptype, qorder, ctx->ds_cnt.as<int>());
-    HIPCHK(hipGetLastError());
-    SPHX_TRY(sphx_excl_scan_int(ctx, ctx->ds_cnt.as<int>(), ctx->ds_start.as<int>(), (int)n));
     out->cnt = ctx->ds_cnt.as<int>(); out->start = ctx->ds_start.as<int>();
-    out->keys = ctx->ds_keys.as<u64>(); out->vals = ctx->ds_vals.as<double>();
+    out->ent = ctx->ds_ent.as<DragEntry>();
+    if (blob) {          // the step's own list with its blob lists: counted out of LDS (sphx_blob.hip)
+        SPHX_TRY(sphx_blob_drag(ctx, n, k, true, nullptr, ptype, nullptr, nullptr, nullptr, nullptr, *out));
+    } else {
+        hipLaunchKernelGGL(drag_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           (int)sphx_pad64(n), k, nbr, ptype, qorder, ctx->ds_cnt.as<int>());
+        HIPCHK(hipGetLastError());
+    }
+    SPHX_TRY(sphx_excl_scan_int(ctx, ctx->ds_cnt.as<int>(), ctx->ds_start.as<int>(), (int)n));
     return SPHX_OK;
 }
 int sphx_drag_scatter_reduce(sphx_ctx* ctx, int64_t n, const DragScatter& d, double* react) {
     const int64_t want = (n + 255) / 256;
     hipLaunchKernelGGL(drag_reduce_kernel, dim3((unsigned)(want < DRAG_RED_BLOCKS ? want : DRAG_RED_BLOCKS)), dim3(256), 0,
-                       ctx->stream, (int)n, d.start, d.keys, d.vals, react);
+                       ctx->stream, (int)n, d.start, d.ent, react);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -544,10 +550,15 @@ __global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, 
     const int i = qorder ? qorder[p] : p;
     const double* rq = reinterpret_cast<const double*>(&recb[i]);
     const Q4 r0 = load4(rq), rv = load4(rq + 4);
-    double ox = 0.0, oy = 0.0, oz = 0.0;
+    // (partial sums over the list positions k mod SPHX_SUM_PARTS, as every sum of the step: the LDS form, sphx_blob.hip
+    //  blob_drag_kernel, keeps one per lane)
+    double a_x[SPHX_SUM_PARTS] = {}, a_y[SPHX_SUM_PARTS] = {}, a_z[SPHX_SUM_PARTS] = {};
     for (int kk = 0; kk < k; ++kk) {
         const int j = nbr[(size_t)kk * npad + p];
         if (j < 0 || ptype[j] != 2.0) continue;                  // dust neighbours only   nsc:736
+        double& ox = a_x[kk & (SPHX_SUM_PARTS - 1)];
+        double& oy = a_y[kk & (SPHX_SUM_PARTS - 1)];
+        double& oz = a_z[kk & (SPHX_SUM_PARTS - 1)];
         const double* qb = reinterpret_cast<const double*>(&recb[j]);
         const Q4 q0 = load4(qb), qv = load4(qb + 4);
         const double dx = q0.a - r0.a, dy = q0.b - r0.b, dz = q0.c - r0.c;
@@ -564,11 +575,10 @@ __global__ __launch_bounds__(256) void pass_drag_kernel(int n, int npad, int k, 
         }
         if (j != i) {                                              // nsc:741 (a zero where the kernel vanishes: counted too)
             const int slot = sc.start[j] + atomicSub(&sc.cnt[j], 1) - 1;
-            sc.keys[slot] = ((u64)(unsigned)id[i] << 8) | (u64)kk;
-            sc.vals[3 * (size_t)slot] = -fx; sc.vals[3 * (size_t)slot + 1] = -fy; sc.vals[3 * (size_t)slot + 2] = -fz;
+            sphx_drag_put(sc, slot, ((u64)(unsigned)id[i] << 8) | (u64)kk, -fx, -fy, -fz);
         }
     }
-    onto[3 * (size_t)i] = ox; onto[3 * (size_t)i + 1] = oy; onto[3 * (size_t)i + 2] = oz;
+    onto[3 * (size_t)i] = parts_total(a_x); onto[3 * (size_t)i + 1] = parts_total(a_y); onto[3 * (size_t)i + 2] = parts_total(a_z);
 }
 
 int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const double* ptype, const double* mgm,
@@ -576,7 +586,13 @@ int sphx_pass_drag(sphx_ctx* ctx, int64_t n, int k, const double* m, const doubl
     SPHX_TRY(sphx_ensure(ctx, ctx->drag_on, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->drag_re, (size_t)n * 3 * sizeof(double)));
     DragScatter sc;
-    SPHX_TRY(sphx_drag_scatter_plan(ctx, n, k, ctx->nbr.as<int>(), ptype, ctx->qorder, &sc));
+    const bool blob = ctx->qorder && ctx->blob_lists && ctx->use_lds && ctx->drag_lds && k <= SPHX_MAX_K;
+    SPHX_TRY(sphx_drag_scatter_plan(ctx, n, k, ctx->nbr.as<int>(), ptype, ctx->qorder, &sc, blob));
+    const int* ids = ctx->map_perm ? ctx->map_perm : ctx->st.id.as<int>();       // the caller's index of a stored particle
+    if (blob) {
+        SPHX_TRY(sphx_blob_drag(ctx, n, k, false, m, ptype, mgm, mcs, ids, ctx->drag_on.as<double>(), sc));
+        return sphx_drag_scatter_reduce(ctx, n, sc, ctx->drag_re.as<double>());
+    }
     hipLaunchKernelGGL(pass_drag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
                        (int)sphx_pad64(n), k, ctx->nbr.as<int>(), ctx->recv.as<RecB>(), m, ptype, mgm, mcs, ctx->qorder,
                        ctx->map_perm ? ctx->map_perm : ctx->st.id.as<int>(),       // the caller's index of a stored particle

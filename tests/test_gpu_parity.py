@@ -378,6 +378,27 @@ def test_step_with_drag_vs_oracle():
         assert np.array_equal(got[key], got2[key]), key
 
 
+@pytest.mark.parametrize("workload,n,forms", [("dusty_sphere", 20000, "hydro_update"), ("two_phase", 30000, "loop")])
+def test_drag_out_of_lds_equals_the_gather_form(workload, n, forms, monkeypatch):
+    """The step's drag pass on the blob lists (sphx_blob.hip blob_drag_kernel: dust flags and reference counts in LDS, one
+    global atomic per distinct dust neighbour and blob for its share of the ordered scatter) against the gather form
+    (sphx_sums.hip pass_drag_kernel, SPHX_DRAG_LDS=0): the same bits, drag on the gas and reaction on the dust."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    s0 = ics.WORKLOADS[workload](n)
+    kw = dict(forms="loop", d=ics.loop_d(s0, 40)) if forms == "loop" else {}
+    res = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("SPHX_DRAG_LDS", v)
+        sim = Simulation(s0, n_neigh=40, with_drag=True, **kw)
+        sim.step(5)
+        res[v] = sim.download()
+    dust = s0["particle_type"] == 2
+    assert dust.sum() > 500 and np.max(np.abs(res["1"]["total_accel"][dust])) > 0.0
+    for key in ("points", "velocities", "total_accel", "E_internal"):
+        assert np.array_equal(res["1"][key], res["0"][key]), key
+
+
 def test_incremental_search_is_exact():
     """Verlet-list refresh (sphx_refresh.hip): with a small fixed dt most steps take the kNN from
     the candidate lists; the trajectory must be bit-identical to the full search every step."""
