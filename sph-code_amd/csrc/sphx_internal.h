@@ -154,6 +154,7 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     DevBuf need_pyr;              // sphx_dev_need_map: widest claim per coarse cell + the pyramid of maxima over it
+    DevBuf loop_side;                            // loop-form pass 1, LDS form: gamma | dust mass | -1 per particle
     DevBuf ds_cnt, ds_start, ds_ent;             // ordered scatter of the reaction (DragScatter)
     const void* ds_cnt_zeroed = nullptr;
     bool drag = false;            // gas-dust drag enabled in the step loop (sphx_state_set_drag)

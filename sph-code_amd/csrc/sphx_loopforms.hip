@@ -600,10 +600,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
                                                                           const int* __restrict__ uniq,
                                                                           const int* __restrict__ qorder,
                                                                           const RecP1* __restrict__ p1,
-                                                                          const double* __restrict__ gam,
-                                                                          const double* __restrict__ pt,
-                                                                          const double* __restrict__ m,
-                                                                          const double* __restrict__ h, double* rho,
+                                                                          const double* __restrict__ side, double* rho,
                                                                           double* rhod, double* nden, double* G,
                                                                           RecP2* p2, BlobSel sel) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, gamma, slot tile
@@ -615,7 +612,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
         const int b = blob_sel_at(sel, bi, nsel);
         const int p = b * BLOB_P + t;
         const int i = (p < n) ? qorder[p] : 0;
-        stage<1>(img, lgam, tile, p1, gam, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
+        stage<1>(img, lgam, tile, p1, side, 1, nullptr, 0, uniq + (size_t)b * BLOB_S, slot16, npad, k, b);
         const double* sp = reinterpret_cast<const double*>(&p1[i]);
         const Q4 s0 = gload4(sp), s1 = gload4(sp + 4);
         __syncthreads();
@@ -644,7 +641,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
                         } else if (sl[u] == SLOT_OVER) {
                             jb[u] = nbr[(size_t)(LPP * (m0 + u) + part) * npad + p];
                             const double* q = reinterpret_cast<const double*>(&p1[jb[u]]);
-                            q0b[u] = gload4(q); q1b[u] = gload4(q + 4); gb[u] = gam[jb[u]];
+                            q0b[u] = gload4(q); q1b[u] = gload4(q + 4); gb[u] = side[jb[u]];
                         } else { q0b[u] = s0; q1b[u] = s1; gb[u] = 1.0; }
                     }
                 }
@@ -652,10 +649,9 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
                 for (int u = 0; u < NB; ++u) {
                     if (sl[u] == SLOT_NONE) continue;
                     double dm = -1.0, dh = 0.0;
-                    if (!(q1b[u].c > 0.0)) {                   // not gas: dust needs its mass and size
-                        const int j = jb[u] >= 0 ? jb[u] : nbr[(size_t)(LPP * (m0 + u) + part) * npad + p];
-                        if (pt[j] == 2.0) { dm = m[j]; dh = h[j]; }
-                    }
+                    // not gas: a dust neighbour's mass travels in the side value, its size in the record's g1 (neither is
+                    // read for a neighbour that is not gas; loop_dust_side_kernel) - nothing is gathered here
+                    if (!(q1b[u].c > 0.0) && gb[u] >= 0.0) { dm = gb[u]; dh = q1b[u].b; }
                     loop1_term(a, q0b[u], q1b[u], gb[u], dm, dh, s0.a, s0.b, s0.c, s1.d, gas_i, d9);
                 }
             }
@@ -790,6 +786,19 @@ static int loop_attr(sphx_ctx* ctx) {
     }
     return SPHX_OK;
 }
+// The LDS form's per-neighbour side value: gamma of a gas particle (del_pressure, nsc:755); for a dust particle its mass,
+// with its size (this step's kNN radius, Weigh2_dust nsc:678) put where the record keeps g1 - a factor that the type
+// mask zeroes for every neighbour that is not gas; -1 for a star.  (The gather form reads type, mass and size directly.)
+__global__ __launch_bounds__(256) void loop_dust_side_kernel(int n, const double* __restrict__ pt, const double* __restrict__ m,
+                                                             const double* __restrict__ h, const double* __restrict__ gam,
+                                                             RecP1* p1, double* side) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = pt[i];
+    if (t == 0.0) { side[i] = gam[i]; return; }
+    if (t == 2.0) { side[i] = m[i]; p1[i].g1 = h[i]; }
+    else side[i] = -1.0;
+}
 // pass 1: h = the neighbours' kNN radii (dust_density, nsc:704-717), sorted order
 static int loop_pass1_launch(sphx_ctx* ctx, int64_t n, int k, double d, StateArrays& st, const double* h) {
     const double d2 = d * d, d4 = d2 * d2, d9 = d4 * d4 * d;               // pow9(d), as the kernels form it
@@ -799,9 +808,12 @@ static int loop_pass1_launch(sphx_ctx* ctx, int64_t n, int k, double d, StateArr
         SPHX_TRY(loop_attr(ctx));
         const int nblk = (npad + BLOB_P - 1) / BLOB_P;
         const int g = sphx_blob_grid(ctx, nblk);
+        SPHX_TRY(sphx_ensure(ctx, ctx->loop_side, (size_t)n * sizeof(double)));
+        hipLaunchKernelGGL(loop_dust_side_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                           st.ptype.as<double>(), st.m.as<double>(), h, st.gam.as<double>(), p1, ctx->loop_side.as<double>());
         hipLaunchKernelGGL(blob_loop1_kernel, dim3(g), dim3(PASS_T), IMG_BYTES(72, k), ctx->stream, (int)n, npad, k, nblk,
                            d9, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, p1,
-                           st.gam.as<double>(), st.ptype.as<double>(), st.m.as<double>(), h,
+                           ctx->loop_side.as<double>(),
                            ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), p2,
                            sphx_blob_sel(ctx, 0));
     } else {
