@@ -422,10 +422,10 @@ __global__ __launch_bounds__(256) void drag_count_kernel(int n, int npad, int k,
 // 64 entries are added by lane 0 alone, smallest remaining key first.
 #define DRAG_RED_BLOCKS 2048
 #define DRAG_RED_U 4                      // entries per lane the wave form holds: slices up to 256 entries
-// the slice [s, s + L) added in key order -> (ax, ay, az), valid in lane 0
+// the slice [s, s + L) added in key order -> component c of the sum in lane c (c = 0, 1, 2)
 template <int U>
 __device__ __forceinline__ void drag_slice_sum(int s, int L, const DragEntry* __restrict__ ent,
-                                               double* pk, int lane, double& ax, double& ay, double& az) {
+                                               double* pk, int lane, double& acc) {
     u64 key[U];
     double vx[U], vy[U], vz[U];
     int rank[U];
@@ -456,8 +456,19 @@ __device__ __forceinline__ void drag_slice_sum(int s, int L, const DragEntry* __
         if (q < L) { pk[3 * rank[u]] = vx[u]; pk[3 * rank[u] + 1] = vy[u]; pk[3 * rank[u] + 2] = vz[u]; }
     }
     wave_sync();
-    if (lane == 0)
-        for (int t = 0; t < L; ++t) { ax += pk[3 * t]; ay += pk[3 * t + 1]; az += pk[3 * t + 2]; }
+    if (lane < 3) {
+        // (in key order, one addition after the other, a lane per component: eight entries' reads are issued together,
+        //  their additions follow)
+        int t = 0;
+        for (; t + 8 <= L; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = pk[3 * (t + q) + lane];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; t < L; ++t) acc += pk[3 * t + lane];
+    }
     wave_sync();
 }
 // A wave takes 64 consecutive receivers at a time: every lane looks up one slice (most are empty: zeros written at once),
@@ -478,11 +489,12 @@ __global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __re
             todo &= todo - 1;
             const int s = __builtin_amdgcn_readlane(sl, t), L = __builtin_amdgcn_readlane(Ll, t);
             const int j = j0 + t;
-            double ax = 0.0, ay = 0.0, az = 0.0;
+            double ax = 0.0, ay = 0.0, az = 0.0, acc = 0.0;
+            const bool by_lane = L <= 64 * DRAG_RED_U;
             if (L <= 64) {
-                drag_slice_sum<1>(s, L, ent, pk, lane, ax, ay, az);
-            } else if (L <= 64 * DRAG_RED_U) {
-                drag_slice_sum<DRAG_RED_U>(s, L, ent, pk, lane, ax, ay, az);
+                drag_slice_sum<1>(s, L, ent, pk, lane, acc);
+            } else if (by_lane) {
+                drag_slice_sum<DRAG_RED_U>(s, L, ent, pk, lane, acc);
             } else if (lane == 0) {                       // a very long slice: smallest remaining key first, one lane
                 u64 last = 0;
                 bool have = false;
@@ -498,7 +510,8 @@ __global__ __launch_bounds__(256) void drag_reduce_kernel(int n, const int* __re
                     have = true;
                 }
             }
-            if (lane == 0) { react[3 * (size_t)j] = ax; react[3 * (size_t)j + 1] = ay; react[3 * (size_t)j + 2] = az; }
+            if (by_lane) { if (lane < 3) react[3 * (size_t)j + lane] = acc; }
+            else if (lane == 0) { react[3 * (size_t)j] = ax; react[3 * (size_t)j + 1] = ay; react[3 * (size_t)j + 2] = az; }
         }
     }
 }
