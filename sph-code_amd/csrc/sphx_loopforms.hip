@@ -463,7 +463,7 @@ __device__ __forceinline__ double loop2_term(L2Acc& a, const Q4& q0, const Q4& q
     if (q0.d < 0.0) return rel;                                                   // sums over gas neighbours only
     const double dx = q0.a - s0.a, dy = q0.b - s0.b, dz = q0.c - s0.c;
     const double r2 = dx * dx + dy * dy + dz * dz;
-    double w = (dvx * dx + dvy * dy + dvz * dz) / sqrt(r2);
+    double w = (dvx * dx + dvy * dy + dvz * dz) / sqrt_mid(r2);                   // (sqrt's bits on this range: sphx_blob.h)
     w = (w > 0.0) ? 0.0 : w;
     w = nan_to_num_d(w);                                                          // self pair: 0/0
     const double vsig = q0.d + s0.d - 3.0 * w;
