@@ -160,7 +160,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
+                     &ctx->loop_side, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -380,12 +380,12 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->s = 0;
     if (f_un) {
         // rows padded to whole 128-B lines (16 doubles for the reference's 15 species): one aligned line per neighbour
-        // in the species pass, vector copies in the permutation
+        // in the species pass; kept in upload order (ctx->fun_id): the pass reaches a row through the particle's id
         const int sp = (s + 15) & ~15;
         SPHX_TRY(upload(ctx, ctx->in_d, f_un, (size_t)n * s * sizeof(double)));
-        SPHX_TRY(sphx_ensure(ctx, st.fun, (size_t)n * sp * sizeof(double)));
-        HIPCHK(hipMemsetAsync(st.fun.p, 0, (size_t)n * sp * sizeof(double), ctx->stream));
-        HIPCHK(hipMemcpy2DAsync(st.fun.p, (size_t)sp * sizeof(double), ctx->in_d.p, (size_t)s * sizeof(double),
+        SPHX_TRY(sphx_ensure(ctx, ctx->fun_id, (size_t)n * sp * sizeof(double)));
+        HIPCHK(hipMemsetAsync(ctx->fun_id.p, 0, (size_t)n * sp * sizeof(double), ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(ctx->fun_id.p, (size_t)sp * sizeof(double), ctx->in_d.p, (size_t)s * sizeof(double),
                                 (size_t)s * sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
         ctx->s = s;
         ctx->sp = sp;
@@ -617,7 +617,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     if (ctx->qorder && ctx->use_lds) SPHX_TRY(sphx_blob_translate(ctx, n, k));
     if (ctx->loop_forms) {
         // the reference's time loop (drv:451-458): loop forms on this step's neighbour list
-        const bool species = ctx->s > 0 && ctx->st.fun.p;      // the species pass reads hydro_update's records (RecA)
+        const bool species = ctx->s > 0 && ctx->fun_id.p;      // the species pass reads hydro_update's records (RecA)
         if (ctx->drag || species)
             SPHX_TRY(sphx_prep(ctx, n, s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), nullptr,
                                s.vx.as<double>(), s.vy.as<double>(), s.vz.as<double>(), nullptr, s.m.as<double>(),
@@ -652,7 +652,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     SPHX_TRY(sphx_pass_density(ctx, n, k));
     if (detail) HIPCHK(hipEventRecord(ev[9], ctx->stream));
     // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un
-    if (ctx->s > 0 && ctx->st.fun.p) SPHX_TRY(sphx_step_species(ctx, n, k));
+    if (ctx->s > 0 && ctx->fun_id.p) SPHX_TRY(sphx_step_species(ctx, n, k));
     if (detail) HIPCHK(hipEventRecord(ev[4], ctx->stream));
     SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
     if (detail) HIPCHK(hipEventRecord(ev[5], ctx->stream));
@@ -876,7 +876,7 @@ extern "C" int sphx_state_set_agb(sphx_ctx* ctx, int nspl, const int32_t* ntx, c
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb before sphx_state_upload");
     ctx->agb_on = false;
     if (nspl == 0) return SPHX_OK;
-    if (ctx->s < 7 || !ctx->st.fun.p)
+    if (ctx->s < 7 || !ctx->fun_id.p)
         return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_agb: the state carries no composition (f_un) of >= 7 species");
     return sphx_agb_table_set(ctx, ctx->s, nspl, ntx, nty, tx, ty, coeffs, mapto, divisor, mu_specie, solar_mass);
 }
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256) void scatter_species_major(int n, int S, const
 }
 extern "C" int sphx_state_download_species(sphx_ctx* ctx, double* F, double* Z, double* agb_dust) {
     if (!ctx) return SPHX_E_ARG;
-    if (!ctx->has_state || ctx->s < 1 || !ctx->st.fun.p || ctx->step_count < 1)
+    if (!ctx->has_state || ctx->s < 1 || !ctx->fun_id.p || ctx->step_count < 1)
         return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_download_species: no species pass has run (state without f_un, "
                                                  "or no step yet)");
     if ((Z || agb_dust) && !ctx->agb_on) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_download_species: no AGB table set");

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int 
                                                               const int* __restrict__ qorder,
                                                               const RecA* __restrict__ rec,
                                                               const double* __restrict__ fun,       // rows of 16 doubles
+                                                              const int* __restrict__ row_of,       // (nullable) row of particle j
                                                               const double* __restrict__ m, AgbTable agb, int agb_on,
                                                               double* F, double* Zout, double* agb_out) {
     extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int 
                 double2 c[NSTAGE][4];
 #pragma unroll
                 for (int r = 0; r < NSTAGE; ++r) {
-                    const double2* g = reinterpret_cast<const double2*>(fun + (size_t)(ju[r] < 0 ? 0 : ju[r]) * 16) + 4 * hh;
+                    const int jr = ju[r] < 0 ? 0 : ju[r];
+                    const double2* g = reinterpret_cast<const double2*>(fun + (size_t)(row_of ? row_of[jr] : jr) * 16) + 4 * hh;
                     c[r][0] = g[0]; c[r][1] = g[1]; c[r][2] = g[2]; c[r][3] = g[3];
                 }
 #pragma unroll
@@ -678,7 +680,8 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int 
                         Q4 f0, f1;
                         if (sl < SLOT_OVER) { f0 = lload4(img, (int)sl, 0); f1 = lload4(img, (int)sl, 1); }
                         else {
-                            const double* q = fun + (size_t)nbr[(size_t)(LPP * mm + half) * npad + p] * 16 + 8 * hh;
+                            const int jo = nbr[(size_t)(LPP * mm + half) * npad + p];
+                            const double* q = fun + (size_t)(row_of ? row_of[jo] : jo) * 16 + 8 * hh;
                             f0 = gload4(q); f1 = gload4(q + 4);
                         }
                         const double wm = w[mm];
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int 
     }
 }
 
-int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_sorted, const double* m_sorted, double* F,
+int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun, const int* row_of, const double* m_sorted, double* F,
                       double* Z, double* agb, int agb_on) {
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
@@ -737,11 +740,11 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_
     if (KPAD(k) / LPP <= 10)
         hipLaunchKernelGGL(blob_species_kernel<10>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n,
                            (int)npad, k, nblk, S, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,
-                           ctx->rec1.as<RecA>(), fun_sorted, m_sorted, ctx->agb, agb_on, F, Z, agb);
+                           ctx->rec1.as<RecA>(), fun, row_of, m_sorted, ctx->agb, agb_on, F, Z, agb);
     else
         hipLaunchKernelGGL(blob_species_kernel<16>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n,
                            (int)npad, k, nblk, S, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder,
-                           ctx->rec1.as<RecA>(), fun_sorted, m_sorted, ctx->agb, agb_on, F, Z, agb);
+                           ctx->rec1.as<RecA>(), fun, row_of, m_sorted, ctx->agb, agb_on, F, Z, agb);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }

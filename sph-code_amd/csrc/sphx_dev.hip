@@ -523,7 +523,7 @@ extern "C" int sphx_dev_species(sphx_ctx* ctx, int nspecies, const double* f_un,
     SPHX_TRY(sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double)));
     hipLaunchKernelGGL(dev_gather_fun_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, S, SP, ctx->map_perm, f_un, mass,
                        st.fun.as<double>(), st.m.as<double>());
-    SPHX_TRY(sphx_species_on(ctx, n, ctx->k, S, SP, st.fun.as<double>(), st.m.as<double>(), ctx->F.as<double>(),
+    SPHX_TRY(sphx_species_on(ctx, n, ctx->k, S, SP, st.fun.as<double>(), nullptr, st.m.as<double>(), ctx->F.as<double>(),
                              Z ? ctx->Zmet.as<double>() : nullptr, Z ? ctx->agb_dust.as<double>() : nullptr));
     hipLaunchKernelGGL(dev_scatter_species_kernel, dim3(grid), dim3(256), 0, ctx->stream, (int)n, S, ctx->map_perm,
                        ctx->map_nactive, ctx->F.as<double>(), F);

@@ -107,11 +107,7 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split, hipEvent_t after_fi
     SPHX_TRY(sphx_ensure(ctx, b.id, (size_t)n * sizeof(int)));
     SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
     g.id_src = a.id.as<int>(); g.id_dst = b.id.as<int>(); g.inv = ctx->inv.as<int>();
-    g.fun_src = nullptr; g.fun_dst = nullptr;
-    if (ctx->s > 0 && a.fun.p) {
-        SPHX_TRY(sphx_ensure(ctx, b.fun, (size_t)n * ctx->sp * sizeof(double)));
-        g.fun_src = a.fun.as<double>(); g.fun_dst = b.fun.as<double>();
-    }
+    g.fun_src = nullptr; g.fun_dst = nullptr;      // (the composition rows are not moved: ctx->fun_id, reached through the id)
     split = split && ctx->side_stream && ctx->ev_perm_fork && ctx->ev_perm;
     GatherArgs rest = g;                       // velocities ... ptype (+ drag coefficients, + composition): side stream
     if (split) {

@@ -154,6 +154,10 @@ struct sphx_ctx {
     DevBuf rho_s, bc_s, self_s;   // sorted-order compact arrays: rho[n], RecBC[n], RecSelf[n]
     DevBuf drag_on, drag_re;      // (n,3) dust->gas drag and its scatter-added reaction (nsc:719-742)
     DevBuf need_pyr;              // sphx_dev_need_map: widest claim per coarse cell + the pyramid of maxima over it
+    // the composition rows f_un (sp doubles each) in the ORDER OF UPLOAD, never permuted: the species pass reaches a row
+    // through the particle's id (128 B per particle and step that the state's permutation does not move - beside the
+    // search, where that copy cost the grouped kernel 84 us on the two-phase cloud)
+    DevBuf fun_id;
     DevBuf loop_side;                            // loop-form pass 1, LDS form: gamma | dust mass | -1 per particle
     DevBuf ds_cnt, ds_start, ds_ent;             // ordered scatter of the reaction (DragScatter)
     const void* ds_cnt_zeroed = nullptr;
@@ -392,7 +396,7 @@ int sphx_blob_join(sphx_ctx* ctx);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);
 int sphx_blob_pi(sphx_ctx* ctx, int64_t n, int k, u64* ct_bits);
 int sphx_blob_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
-int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun_sorted, const double* m_sorted, double* F,
+int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun, const int* row_of, const double* m_sorted, double* F,
                       double* Z, double* agb, int agb_on);
 int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const double* y,
                     const double* z, double cell_hint);   // fills grid, cell_start, perm
@@ -441,8 +445,9 @@ int sphx_pass_pi(sphx_ctx* ctx, int64_t n, int k, const double* h, const double*
 int sphx_pass_visc(sphx_ctx* ctx, int64_t n, int k, const double* m);
 int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun, double* F);
 int sphx_step_species(sphx_ctx* ctx, int64_t n, int k);
-int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun_sorted, const double* m_sorted, double* F,
-                    double* Z, double* agb);
+// fun: composition rows; row_of (nullable: identity): the row of sorted particle j is fun + row_of[j] * SP
+int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun, const int* row_of, const double* m_sorted,
+                    double* F, double* Z, double* agb);
 int sphx_agb_table_set(sphx_ctx* ctx, int S, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx, const double* ty,
                        const double* coeffs, const int32_t* mapto, double divisor, const double* mu_specie, double solar_mass);
 int sphx_transpose_nbr(sphx_ctx* ctx, int64_t n, int k, const int64_t* nb_rowmajor);

@@ -673,6 +673,7 @@ int sphx_pass_species(sphx_ctx* ctx, int64_t n, int k, int s, const double* fun,
 template <int SMAX>
 __global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int k, int S, int SP, const int* __restrict__ nbr,
                                                            const RecA* __restrict__ rec, const double* __restrict__ fun,
+                                                           const int* __restrict__ row_of,
                                                            const int* __restrict__ qorder, const double* __restrict__ m,
                                                            AgbTable agb, int agb_on, double* F, double* Zout,
                                                            double* agb_out) {
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int 
         for (int u = 0; u < 4; ++u) {
             if (jb[u] < 0) continue;
             // (rows are padded with zeros to SP doubles, whole 128-B lines: no bound test, 16-B loads)
-            const double2* f = reinterpret_cast<const double2*>(fun + (size_t)jb[u] * SP);
+            const double2* f = reinterpret_cast<const double2*>(fun + (size_t)(row_of ? row_of[jb[u]] : jb[u]) * SP);
 #pragma unroll
             for (int t = 0; t < SMAX / 2; ++t) {
                 if (2 * t < SP) {
@@ -740,20 +741,20 @@ __global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int 
 }
 
 // the species pass on any set of sorted arrays (the step: the resident state; the device API: gathered copies)
-int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun_sorted, const double* m_sorted, double* F,
-                    double* Z, double* agb) {
+int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun, const int* row_of, const double* m_sorted,
+                    double* F, double* Z, double* agb) {
     int agb_on = (ctx->agb_on && Z && agb) ? 1 : 0;
     if (getenv("SPHX_EXP_NO_AGB")) agb_on = 0;          // timing experiment: the species sums alone
     // out of LDS when the step's blob lists are at hand (sphx_blob.hip); the gather form below otherwise
     if (ctx->use_lds && ctx->blob_lists && ctx->qorder && SP == 16 && S <= 16 && k <= SPHX_MAX_K && ctx->species_lds)
-        return sphx_blob_species(ctx, n, k, S, fun_sorted, m_sorted, F, Z, agb, agb_on);
+        return sphx_blob_species(ctx, n, k, S, fun, row_of, m_sorted, F, Z, agb, agb_on);
     if (S <= 16)       // the reference's 15 species: sums in 16 registers
         hipLaunchKernelGGL(step_species_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                           (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun_sorted, ctx->qorder,
+                           (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun, row_of, ctx->qorder,
                            m_sorted, ctx->agb, agb_on, F, Z, agb);
     else
         hipLaunchKernelGGL(step_species_kernel<SPHX_MAX_SPECIES>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (int)n, (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun_sorted, ctx->qorder,
+                           (int)n, (int)sphx_pad64(n), k, S, SP, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(), fun, row_of, ctx->qorder,
                            m_sorted, ctx->agb, agb_on, F, Z, agb);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -766,6 +767,7 @@ int sphx_step_species(sphx_ctx* ctx, int64_t n, int k) {
         SPHX_TRY(sphx_ensure(ctx, ctx->Zmet, (size_t)n * sizeof(double)));
         SPHX_TRY(sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double)));
     }
-    return sphx_species_on(ctx, n, k, S, ctx->sp, ctx->st.fun.as<double>(), ctx->st.m.as<double>(), ctx->F.as<double>(),
+    // (the rows stay where the upload put them: sorted particle j's row is the one of its id)
+    return sphx_species_on(ctx, n, k, S, ctx->sp, ctx->fun_id.as<double>(), ctx->st.id.as<int>(), ctx->st.m.as<double>(), ctx->F.as<double>(),
                            ctx->Zmet.as<double>(), ctx->agb_dust.as<double>());
 }
