@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void gather3_aos_kernel(int n, const int* perm
     if (t >= n) return;
     const int p = perm[t];
     xs[t] = aos[3 * (size_t)p]; ys[t] = aos[3 * (size_t)p + 1]; zs[t] = aos[3 * (size_t)p + 2];
-    inv[p] = t;
+    if (inv) inv[p] = t;
 }
 
 // dst[s * stride] = src[perm[s]]: caller-order values into a sorted-order compact array
@@ -92,9 +92,8 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     const int rc_grid = sphx_build_grid(ctx, n, k, x, y, z, cell_hint);
     ctx->lag_on = false;
     SPHX_TRY(rc_grid);
-    SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
     hipLaunchKernelGGL(gather3_aos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (int)n, ctx->perm.as<int>(), pos, xs, ys, zs, ctx->inv.as<int>());
+                       (int)n, ctx->perm.as<int>(), pos, xs, ys, zs, (int*)nullptr);
     HIPCHK(hipGetLastError());
     SPHX_TRY(sphx_ensure(ctx, ctx->nbr, (size_t)k * sphx_pad64(n) * sizeof(int)));
     ctx->map_perm = ctx->perm.as<int>();

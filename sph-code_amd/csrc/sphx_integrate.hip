@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     if (a.id_src) {
         const int id = a.id_src[p];
         a.id_dst[t] = id;
-        a.inv[id] = t;
+        if (a.inv) a.inv[id] = t;
     }
     if (a.fun_src) {                       // rows of a.s doubles, a multiple of 16: aligned 16-B copies
         const double2* src = reinterpret_cast<const double2*>(a.fun_src + (size_t)p * a.s);
@@ -105,8 +105,8 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split, hipEvent_t after_fi
         g.narr = 18;
     }
     SPHX_TRY(sphx_ensure(ctx, b.id, (size_t)n * sizeof(int)));
-    SPHX_TRY(sphx_ensure(ctx, ctx->inv, (size_t)n * sizeof(int)));
-    g.id_src = a.id.as<int>(); g.id_dst = b.id.as<int>(); g.inv = ctx->inv.as<int>();
+    // (no inverse permutation: nothing in the step reads one - a scattered 4-byte store per particle saved)
+    g.id_src = a.id.as<int>(); g.id_dst = b.id.as<int>(); g.inv = nullptr;
     g.fun_src = nullptr; g.fun_dst = nullptr;      // (the composition rows are not moved: ctx->fun_id, reached through the id)
     split = split && ctx->side_stream && ctx->ev_perm_fork && ctx->ev_perm;
     GatherArgs rest = g;                       // velocities ... ptype (+ drag coefficients, + composition): side stream
