@@ -160,7 +160,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
+                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -524,7 +524,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             }
             if (ctx->lag_hvalid[ctx->lag_hslot]) {       // the same copy carries the previous search's counters
                 const u64* sv = (const u64*)hs;           // slots SC_HSUM ..: [5] SC_NFAILQ [6] SC_SHORT [7] SC_FARQ [8] SC_BADHINT
-                for (int q = 0; q < 4; ++q) ctx->knn_lag[q] = sv[(SC_NFAILQ - SC_HSUM) + q];
+                for (int q = 0; q < 5; ++q) ctx->knn_lag[q] = sv[(SC_NFAILQ - SC_HSUM) + q];      // .. SC_CROWDED
                 ctx->knn_lag_valid = true;
             }
             const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
@@ -606,7 +606,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         SPHX_TRY(rc_h);
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
-                              (SC_BADHINT - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
+                              (SC_CROWDED - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
         HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
         ctx->lag_halias[hsl] = nullptr;
         ctx->lag_hvalid[hsl] = true;

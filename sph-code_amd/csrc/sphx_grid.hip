@@ -365,6 +365,37 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
 // tie-breaking is lost).  Every lane of the wave must call this (cnt = 0: nothing to do).
 #define CELL_SORT_SERIAL 16
 #define CELL_SORT_WAVE 512
+#define CROWDED_LIST_MIN 2048      // crowded cells at the last build the host knows of, from which they get a launch of their own
+// one crowded cell (m members from perm[bs]) by the whole wave: U = members per lane
+template <int U>
+__device__ __forceinline__ void sort_crowded_cell(int* perm, int bs, int m, int lane) {
+    int v[U], rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = lane + 64 * u;
+        v[u] = q < m ? perm[bs + q] : 0x7FFFFFFF;
+        rank[u] = 0;
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < U; ++c2) {
+        const int lc = m - 64 * c2 < 64 ? m - 64 * c2 : 64;
+        for (int tt = 0; tt < lc; ++tt) {
+            const int kt = __builtin_amdgcn_readlane(v[c2], tt);
+#pragma unroll
+            for (int u = 0; u < U; ++u) rank[u] += kt < v[u] ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (lane + 64 * u < m) perm[bs + rank[u]] = v[u];
+}
+// (the comparisons go as members x members-per-lane: a cell of 40 is not charged for a cell of 512)
+__device__ __forceinline__ void sort_crowded_cell_any(int* perm, int bs, int m, int lane) {
+    if (m <= 64) sort_crowded_cell<1>(perm, bs, m, lane);
+    else if (m <= 128) sort_crowded_cell<2>(perm, bs, m, lane);
+    else if (m <= 256) sort_crowded_cell<4>(perm, bs, m, lane);
+    else sort_crowded_cell<8>(perm, bs, m, lane);
+}
 __device__ __forceinline__ void sort_cell_members(int* perm, int s, int cnt, bool on) {
     if (on && cnt > 1 && cnt <= CELL_SORT_SERIAL) {
         for (int i = s + 1; i < s + cnt; ++i) {
@@ -380,26 +411,7 @@ __device__ __forceinline__ void sort_cell_members(int* perm, int s, int cnt, boo
         const int t = __builtin_ctzll(big);
         big &= big - 1;
         const int bs = __builtin_amdgcn_readlane(s, t), m = __builtin_amdgcn_readlane(cnt, t);
-        constexpr int U = CELL_SORT_WAVE / 64;
-        int v[U], rank[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = lane + 64 * u;
-            v[u] = q < m ? perm[bs + q] : 0x7FFFFFFF;
-            rank[u] = 0;
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < U; ++c2) {
-            const int lc = m - 64 * c2 < 64 ? m - 64 * c2 : 64;
-            for (int tt = 0; tt < lc; ++tt) {
-                const int kt = __builtin_amdgcn_readlane(v[c2], tt);
-#pragma unroll
-                for (int u = 0; u < U; ++u) rank[u] += kt < v[u] ? 1 : 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (lane + 64 * u < m) perm[bs + rank[u]] = v[u];
+        sort_crowded_cell_any(perm, bs, m, lane);
     }
 }
 __global__ __launch_bounds__(256) void cell_sort_members(int ncells, const int* cell_start, int* perm) {
@@ -697,15 +709,45 @@ int sphx_build_outlier_levels(sphx_ctx* ctx, int64_t n, const double* xs, const 
 // interleaved from the least significant end, each axis contributing only the bits it has, so the code
 // space is at most 8x the cell count whatever the grid's aspect ratio.
 // one thread per cell; sort_perm != nullptr: also sorts the cell's members (cell_sort_members, deferred to here)
+// crowded != nullptr: cells of 17 .. 512 members are not sorted here but listed (crowded[0] = how many, then their
+// indices) for cell_sort_crowded - a wave sorts its crowded cells one after the other, and the crowded cells of a cloud
+// with a dense core sit together: 64 in one wave and none in the next was 0.24 ms of a launch that takes 0.03
 __global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, const int* cell_start, int* mcount,
-                                                  int* sort_perm) {
+                                                  int* sort_perm, int* crowded, u64* counters) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     int s0 = 0, cnt = 0;
     if (c < g.ncells) { s0 = cell_start[c]; cnt = cell_start[c + 1] - s0; }
-    sort_cell_members(sort_perm, s0, cnt, sort_perm != nullptr);       // (the whole wave: crowded cells are sorted together)
+    if (sort_perm) {          // how many crowded cells there are: the host's cue (a step late) for the list form
+        const u64 bm0 = __builtin_amdgcn_ballot_w64(cnt > CELL_SORT_SERIAL && cnt <= CELL_SORT_WAVE);
+        if (bm0 && counters && (threadIdx.x & 63) == 0) atomicAdd(&counters[SC_CROWDED], (u64)__popcll(bm0));
+    }
+    if (sort_perm && crowded) {
+        sort_cell_members(sort_perm, s0, cnt <= CELL_SORT_SERIAL ? cnt : 0, true);
+        const bool big = cnt > CELL_SORT_SERIAL && cnt <= CELL_SORT_WAVE;
+        const u64 bm = __builtin_amdgcn_ballot_w64(big);
+        if (bm) {
+            int base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(crowded, __popcll(bm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (big) crowded[1 + base + __popcll(bm & ((1ull << (threadIdx.x & 63)) - 1ull))] = c;
+        }
+    } else {
+        sort_cell_members(sort_perm, s0, cnt, sort_perm != nullptr);   // (the whole wave: crowded cells are sorted together)
+    }
     if (cnt == 0) return;
     const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
     mcount[blob_rank(cx, cy, cz, b)] = cnt;
+}
+// one wave per listed cell
+__global__ __launch_bounds__(256) void cell_sort_crowded(const int* __restrict__ crowded, const int* __restrict__ cell_start,
+                                                         int* perm) {
+    const int total = crowded[0];
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += gridDim.x * 4) {
+        const int c = crowded[1 + e];
+        const int s = cell_start[c];
+        sort_crowded_cell_any(perm, s, cell_start[c + 1] - s, lane);
+    }
 }
 __global__ __launch_bounds__(256) void blob_scatter(int n, GridParams g, BlobBits b, const int* cell_of,
                                                     const int* perm, const int* cell_start, const int* mstart,
@@ -753,8 +795,20 @@ int sphx_build_blob_order(sphx_ctx* ctx, int64_t n) {
         HIPCHK(hipMemsetAsync(mc, 0, ctx->mcount.cap, ctx->stream));
     }
     ctx->mcount_zeroed = nullptr;
+    int* crowded = nullptr;
+    // many crowded cells (a dense core: they sit together, 64 to a wave) are sorted by a launch of their own, one wave
+    // per cell; a few are sorted where they are found (two launches less: the headline's case)
+    if (ctx->cells_unsorted && ctx->crowded_last >= CROWDED_LIST_MIN) {          // (a crowded cell has >= 17 members: at most n / 17 of them)
+        SPHX_TRY(sphx_ensure(ctx, ctx->crowded, ((size_t)n / 17 + 2) * sizeof(int)));
+        crowded = ctx->crowded.as<int>();
+        HIPCHK(hipMemsetAsync(crowded, 0, sizeof(int), ctx->stream));
+    }
     hipLaunchKernelGGL(blob_count, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, ctx->stream, g, b,
-                       ctx->cell_start.as<int>(), mc, ctx->cells_unsorted ? ctx->perm.as<int>() : nullptr);
+                       ctx->cell_start.as<int>(), mc, ctx->cells_unsorted ? ctx->perm.as<int>() : nullptr, crowded,
+                       ctx->scal.as<u64>());
+    if (crowded)
+        hipLaunchKernelGGL(cell_sort_crowded, dim3(1024), dim3(256), 0, ctx->stream, crowded, ctx->cell_start.as<int>(),
+                           ctx->perm.as<int>());
     ctx->cells_unsorted = false;
     SPHX_TRY(excl_scan_plus_total(ctx, mc, ms, M));
     if (ctx->defer_blob_scatter) {

@@ -158,6 +158,7 @@ struct sphx_ctx {
     // through the particle's id (128 B per particle and step that the state's permutation does not move - beside the
     // search, where that copy cost the grouped kernel 84 us on the two-phase cloud)
     DevBuf fun_id;
+    DevBuf crowded;                              // cells of 17 .. 512 members, listed by blob_count for cell_sort_crowded
     DevBuf loop_side;                            // loop-form pass 1, LDS form: gamma | dust mass | -1 per particle
     DevBuf ds_cnt, ds_start, ds_ent;             // ordered scatter of the reaction (DragScatter)
     const void* ds_cnt_zeroed = nullptr;
@@ -227,7 +228,9 @@ struct sphx_ctx {
     int64_t list_len_last = 0;      // queries the previous hinted search left to the general kernel (sizes the list-mode grid)
     bool knn_lag_external = false;  // the caller copies SC_NFAILQ .. SC_BADHINT out behind the search and hands them back
     bool knn_lag_valid = false;
-    u64 knn_lag[4] = {0, 0, 0, 0};
+    u64 knn_lag[5] = {0, 0, 0, 0, 0};
+    u64 crowded_seen = 0;           // SC_CROWDED as last read (the counter only grows)
+    int64_t crowded_last = 0;       // cells of 17 .. 512 members at the last grid build the host knows of
     // hint distrust (an experiment kept as an option, off by default): skip the grouped kernel and seed every radius
     // from the local cell counts.  Auto mode enters when the previous hinted search left more than a quarter of its
     // queries to the general kernel (a diverging run: particles move by several h per step) and leaves once fewer than
@@ -371,6 +374,7 @@ enum {
     SC_SHORT = 10,    // u64: searches that gave up (KNN_MAX_TRIES radii) with fewer than K neighbours although more exist
     SC_FARQ = 11,     // u64, only grows: queries outside the grid box with a search sphere wider than OLEV_MIN_RC cells
     SC_BADHINT = 12,  // u64, only grows: hinted queries (distrust mode) whose radius came out beyond [0.5, 1.5] x the hint
+    SC_CROWDED = 13,  // u64, only grows: cells of 17 .. 512 members met by blob_count (sorted by a launch of their own when many)
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
     SC_KNNPROF = 24,  // u64[16]: general search, cycles / queries / longest / tries by query class (-DSPHX_KNN_PROF builds)
     SC_NSLOTS = 48
