@@ -88,6 +88,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = getenv("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
     if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
     if (const char* e = getenv("SPHX_MAX_CELLS")) ctx->max_cells = atoll(e);
+    if (const char* e = getenv("SPHX_CELL_FEEDBACK")) ctx->cell_feedback = atoi(e) != 0;
+    if (const char* e = getenv("SPHX_CELL_FB_HI")) ctx->cell_fb_hi = atof(e);
+    if (const char* e = getenv("SPHX_CELL_FB_LO")) ctx->cell_fb_lo = atof(e);
     if (const char* e = getenv("SPHX_DRAG_LDS")) ctx->drag_lds = atoi(e) != 0;
     if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
     if (const char* e = getenv("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
@@ -524,12 +527,21 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             }
             if (ctx->lag_hvalid[ctx->lag_hslot]) {       // the same copy carries the previous search's counters
                 const u64* sv = (const u64*)hs;           // slots SC_HSUM ..: [5] SC_NFAILQ [6] SC_SHORT [7] SC_FARQ [8] SC_BADHINT
-                for (int q = 0; q < 5; ++q) ctx->knn_lag[q] = sv[(SC_NFAILQ - SC_HSUM) + q];      // .. SC_CROWDED
+                for (int q = 0; q < 10; ++q) ctx->knn_lag[q] = sv[(SC_NFAILQ - SC_HSUM) + q];      // .. SC_KGDBG + 2
                 ctx->knn_lag_valid = true;
             }
             const double hmean = hs[3] > 0.0 ? hs[0] / hs[3] : 0.0;
             if (hmean > 0.0 && isfinite(hmean)) {
-                cell_hint = ctx->cell_factor * hmean;
+                // SPHX_CELL_FEEDBACK: when a sizeable share of the particles lives in cells of >= DENSE_CELL members (a core
+                // much denser than the mean radius suggests: the 27 cells around a group overflow its tile and the search hands
+                // the group's queries on), the cells shrink, 3 % a step; they relax again, 1 % a step, once that share is small.
+                // (A property of the positions alone: every variant of the search sees the same grid.)
+                if (ctx->cell_feedback) {
+                    const double dense = (double)ctx->densep_last / (double)n;
+                    if (dense > ctx->cell_fb_hi) ctx->cell_scale = fmax(ctx->cell_scale * 0.97, 0.35);
+                    else if (dense < ctx->cell_fb_lo) ctx->cell_scale = fmin(ctx->cell_scale * 1.01, 1.0);
+                }
+                cell_hint = ctx->cell_factor * ctx->cell_scale * hmean;
                 ctx->h_clip = ctx->h_clip_factor * hmean;
             }
         }
@@ -606,7 +618,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         SPHX_TRY(rc_h);
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
-                              (SC_CROWDED - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
+                              (SC_KGDBG + 2 - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
         HIPCHK(hipEventRecord(ctx->lag_hev[hsl], hs_stream));
         ctx->lag_halias[hsl] = nullptr;
         ctx->lag_hvalid[hsl] = true;

@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
 // tie-breaking is lost).  Every lane of the wave must call this (cnt = 0: nothing to do).
 #define CELL_SORT_SERIAL 16
 #define CELL_SORT_WAVE 512
+#define DENSE_CELL 48              // members from which a cell counts as dense (27 of them: 1300, a tile holds 1408)
 #define CROWDED_LIST_MIN 2048      // crowded cells at the last build the host knows of, from which they get a launch of their own
 // one crowded cell (m members from perm[bs]) by the whole wave: U = members per lane
 template <int U>
@@ -720,6 +721,12 @@ __global__ __launch_bounds__(256) void blob_count(GridParams g, BlobBits b, cons
     if (sort_perm) {          // how many crowded cells there are: the host's cue (a step late) for the list form
         const u64 bm0 = __builtin_amdgcn_ballot_w64(cnt > CELL_SORT_SERIAL && cnt <= CELL_SORT_WAVE);
         if (bm0 && counters && (threadIdx.x & 63) == 0) atomicAdd(&counters[SC_CROWDED], (u64)__popcll(bm0));
+        if (bm0 && counters) {            // particles in dense cells: the host's cue for finer cells (sphx_api.hip)
+            int dp = cnt >= DENSE_CELL ? cnt : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dp += __shfl_xor(dp, o, 64);
+            if (dp && (threadIdx.x & 63) == 0) atomicAdd(&counters[SC_DENSEP], (u64)dp);
+        }
     }
     if (sort_perm && crowded) {
         sort_cell_members(sort_perm, s0, cnt <= CELL_SORT_SERIAL ? cnt : 0, true);

@@ -228,8 +228,12 @@ struct sphx_ctx {
     int64_t list_len_last = 0;      // queries the previous hinted search left to the general kernel (sizes the list-mode grid)
     bool knn_lag_external = false;  // the caller copies SC_NFAILQ .. SC_BADHINT out behind the search and hands them back
     bool knn_lag_valid = false;
-    u64 knn_lag[5] = {0, 0, 0, 0, 0};
+    u64 knn_lag[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // slots SC_NFAILQ .. SC_KGDBG + 2
+    u64 densep_seen = 0;            // SC_DENSEP as last read
+    int64_t densep_last = 0;        // particles in cells of >= DENSE_CELL members at the last grid build the host knows of
     u64 crowded_seen = 0;           // SC_CROWDED as last read (the counter only grows)
+    bool cell_feedback = true;      // SPHX_CELL_FEEDBACK=0 switches it off: cells shrink while groups' tiles overflow (sphx_api.hip)
+    double cell_scale = 1.0, cell_fb_hi = 0.30, cell_fb_lo = 0.10;     // (SPHX_CELL_FB_HI / _LO)
     int64_t crowded_last = 0;       // cells of 17 .. 512 members at the last grid build the host knows of
     // hint distrust (an experiment kept as an option, off by default): skip the grouped kernel and seed every radius
     // from the local cell counts.  Auto mode enters when the previous hinted search left more than a quarter of its
@@ -375,6 +379,7 @@ enum {
     SC_FARQ = 11,     // u64, only grows: queries outside the grid box with a search sphere wider than OLEV_MIN_RC cells
     SC_BADHINT = 12,  // u64, only grows: hinted queries (distrust mode) whose radius came out beyond [0.5, 1.5] x the hint
     SC_CROWDED = 13,  // u64, only grows: cells of 17 .. 512 members met by blob_count (sorted by a launch of their own when many)
+    SC_DENSEP = 14,   // u64, only grows: particles in cells of >= DENSE_CELL members (a tile's 27 such cells overflow it)
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
     SC_KNNPROF = 24,  // u64[16]: general search, cycles / queries / longest / tries by query class (-DSPHX_KNN_PROF builds)
     SC_NSLOTS = 48

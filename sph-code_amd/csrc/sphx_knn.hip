@@ -787,6 +787,8 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             ctx->badhint_seen = v[3];
             ctx->crowded_last = (int64_t)(v[4] >= ctx->crowded_seen ? v[4] - ctx->crowded_seen : v[4]);
             ctx->crowded_seen = v[4];
+            ctx->densep_last = (int64_t)(v[5] >= ctx->densep_seen ? v[5] - ctx->densep_seen : v[5]);
+            ctx->densep_seen = v[5];
             if (ctx->distrust_mode == 2) {
                 if (!ctx->distrust) ctx->distrust = fb * 4 > n;
                 else ctx->distrust = bad * 20 > n;
@@ -857,7 +859,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         }
         if (lagged && !ext) {
             if (!ctx->olev_ev) HIPCHK(hipEventCreateWithFlags(&ctx->olev_ev, hipEventDisableTiming));
-            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 3072, ctx->scal.as<u64>() + SC_NFAILQ, 5 * sizeof(u64), hipMemcpyDeviceToHost,
+            HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 3072, ctx->scal.as<u64>() + SC_NFAILQ, 10 * sizeof(u64), hipMemcpyDeviceToHost,
                                   ctx->stream));
             HIPCHK(hipEventRecord(ctx->olev_ev, ctx->stream));
             ctx->olev_ev_valid = true;
