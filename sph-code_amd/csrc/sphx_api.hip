@@ -536,12 +536,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                 // much denser than the mean radius suggests: the 27 cells around a group overflow its tile and the search hands
                 // the group's queries on), the cells shrink, 3 % a step; they relax again, 1 % a step, once that share is small.
                 // (A property of the positions alone: every variant of the search sees the same grid.)
-                if (ctx->cell_feedback) {
-                    const double dense = (double)ctx->densep_last / (double)n;
-                    if (dense > ctx->cell_fb_hi) ctx->cell_scale = fmax(ctx->cell_scale * 0.97, 0.35);
-                    else if (dense < ctx->cell_fb_lo) ctx->cell_scale = fmin(ctx->cell_scale * 1.01, 1.0);
-                }
-                cell_hint = ctx->cell_factor * ctx->cell_scale * hmean;
+                cell_hint = ctx->cell_factor * sphx_cell_feedback(ctx, n) * hmean;
                 ctx->h_clip = ctx->h_clip_factor * hmean;
             }
         }

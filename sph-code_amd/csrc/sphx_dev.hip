@@ -85,7 +85,7 @@ extern "C" int sphx_dev_search(sphx_ctx* ctx, int64_t n_total, int64_t n_owned, 
     double *xs = ctx->in_e.as<double>(), *ys = ctx->in_f.as<double>(), *zs = ctx->in_g.as<double>();
     SPHX_TRY(sphx_aos_to_soa3(ctx, n, pos, x, y, z));
     double cell_hint = 0.0;
-    if (ctx->dev_hmean > 0.0) cell_hint = ctx->cell_factor * ctx->dev_hmean;
+    if (ctx->dev_hmean > 0.0) cell_hint = ctx->cell_factor * sphx_cell_feedback(ctx, n) * ctx->dev_hmean;
     // grid sized from the previous search's box statistics (sphx_grid.hip): the decomposed driver's step
     // then has ONE host wait - its end-of-step scalars - and the host queues the whole step ahead of the GPU
     ctx->lag_on = true;

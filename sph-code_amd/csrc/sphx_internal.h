@@ -399,6 +399,15 @@ int sphx_gravity_tree_launch(sphx_ctx* ctx, int64_t n, const double* x, const do
 int sphx_dev_collect(sphx_ctx* ctx);
 int sphx_loop_step_sums(sphx_ctx* ctx, int64_t n, int k, double d);
 int sphx_build_blob_order(sphx_ctx* ctx, int64_t n);
+// the factor on the cell size for the next grid over n particles (cell_scale, moved one step by the last known dense share)
+static inline double sphx_cell_feedback(sphx_ctx* ctx, int64_t n) {
+    if (ctx->cell_feedback && n > 0) {
+        const double dense = (double)ctx->densep_last / (double)n;
+        if (dense > ctx->cell_fb_hi) ctx->cell_scale = ctx->cell_scale * 0.97 > 0.35 ? ctx->cell_scale * 0.97 : 0.35;
+        else if (dense < ctx->cell_fb_lo) ctx->cell_scale = ctx->cell_scale * 1.01 < 1.0 ? ctx->cell_scale * 1.01 : 1.0;
+    }
+    return ctx->cell_scale;
+}
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
 // device API: the main stream waits for the slot lists of the last search (built beside the record build / the h_j phase)
 int sphx_blob_join(sphx_ctx* ctx);
