@@ -656,7 +656,10 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         }
     }
     if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
-    SPHX_TRY(sphx_pass_density(ctx, n, k));
+    ctx->lean_outputs = true;          // (nothing in the step reads G: hydro_accel = G / rho is what the update takes)
+    const int rc_dens = sphx_pass_density(ctx, n, k);
+    ctx->lean_outputs = false;
+    SPHX_TRY(rc_dens);
     if (detail) HIPCHK(hipEventRecord(ev[9], ctx->stream));
     // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un
     if (ctx->s > 0 && ctx->fun_id.p) SPHX_TRY(sphx_step_species(ctx, n, k));

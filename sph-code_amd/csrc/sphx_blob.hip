@@ -335,7 +335,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int 
             } else if (!half) {
                 rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
                 rho_s[i] = s_rho;                                     // storage order: staged by pass 2
-                G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
+                if (G) { G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz; }
                 ha[3 * (size_t)o + 0] = -gx / s_rho;                  // nsc:619
                 ha[3 * (size_t)o + 1] = -gy / s_rho;
                 ha[3 * (size_t)o + 2] = -gz / s_rho;
@@ -986,7 +986,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->rho.as<double>(),
-                       ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->G.as<double>(), ctx->ha.as<double>(),
+                       ctx->rhod.as<double>(), ctx->nden.as<double>(), ctx->lean_outputs ? nullptr : ctx->G.as<double>(), ctx->ha.as<double>(),
                        sphx_blob_sel(ctx, ctx->pass_part));
     HIPCHK(hipGetLastError());
     return SPHX_OK;

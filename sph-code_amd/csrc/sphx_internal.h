@@ -232,6 +232,7 @@ struct sphx_ctx {
     u64 densep_seen = 0;            // SC_DENSEP as last read
     int64_t densep_last = 0;        // particles in cells of >= DENSE_CELL members at the last grid build the host knows of
     u64 crowded_seen = 0;           // SC_CROWDED as last read (the counter only grows)
+    bool lean_outputs = false;      // the step loop: the pressure term itself (G; hydro_update returns G / rho) is not stored
     bool cell_feedback = true;      // SPHX_CELL_FEEDBACK=0 switches it off: cells shrink while groups' tiles overflow (sphx_api.hip)
     double cell_scale = 1.0, cell_fb_hi = 0.30, cell_fb_lo = 0.10;     // (SPHX_CELL_FB_HI / _LO)
     int64_t crowded_last = 0;       // cells of 17 .. 512 members at the last grid build the host knows of

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
     const double gx = parts_total(a_gx), gy = parts_total(a_gy), gz = parts_total(a_gz);
     rho[o] = s_rho; rhod[o] = s_rd; nden[o] = s_n;
     rho_s[i] = s_rho;                                         // sorted order: gathered by pass 2
-    G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz;
+    if (G) { G[3 * (size_t)o + 0] = -gx; G[3 * (size_t)o + 1] = -gy; G[3 * (size_t)o + 2] = -gz; }
     ha[3 * (size_t)o + 0] = -gx / s_rho;                      // nsc:619
     ha[3 * (size_t)o + 1] = -gy / s_rho;
     ha[3 * (size_t)o + 2] = -gz / s_rho;
@@ -232,7 +232,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
                        (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->qorder, OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
                        ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(),
-                       ctx->G.as<double>(), ctx->ha.as<double>());
+                       ctx->lean_outputs ? nullptr : ctx->G.as<double>(), ctx->ha.as<double>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
