@@ -22,23 +22,35 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# What the search kernels are bound by is vector-instruction ISSUE, and the instructions they are made of - v_pk_fma_f32 /
+# v_pk_add_f32 (phase A), v_min_u32 / v_max_u32 (the ordering network), v_alignbit - each hold a SIMD for 4 cycles
+# (measured: tools/valurate.hip, profiles/r03_valu_rates.txt; only the plain f32 / add forms issue in 2).  Peak in those
+# units: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles.
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0          # = 614.4 G wave-instructions/s
 # algorithmic bytes per particle-step, K = 40, int32 indices internally
 B_SEARCH = 24 + 4 * 40 + 8       # R pos, W idx, W h                       = 192
 B_STEP_CORE = 1248               # search + 3 passes + integrator
 B_STEP_SPECIES = 1488            # + species pass (R f_un 120, W F 120)
 
 
-def search_profile(n, k):
-    """Counters of the search launches from the committed rocprofv3 --pmc profile of this same command
-    (profiles/latest_search_profile.json: HBM-side bytes, VALU issue fraction), or {} when it is for another size.
+def workload_tag(workload, forms, species, drag):
+    return workload + ("_loop" if forms == "loop" else "") + ("_species" if species else "") + ("_drag" if drag else "")
+
+
+def search_profile(tag, n, k):
+    """Counters of the search launches from the committed rocprofv3 --pmc profile of THIS workload's command
+    (profiles/latest_<tag>_profile.json, written by tools/make_search_profile.py from a tools/pmc_profile.sh run: HBM-side
+    bytes, VALU issue fraction, instructions per query), or {} when there is none for this workload and size.
     These are PROFILED numbers of the same build, not measured in this run - labelled so in the bench line."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "latest_search_profile.json")) as f:
-            t = json.load(f)
-        if int(t["n"]) == int(n) and int(t["k"]) == int(k):
-            return t
-    except Exception:
-        pass
+    names = ["latest_%s_profile.json" % tag] + (["latest_search_profile.json"] if tag == "polytrope" else [])
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if int(t["n"]) == int(n) and int(t["k"]) == int(k):
+                return t
+        except Exception:
+            pass
     return {}
 
 
@@ -171,6 +183,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = sim.stats()
+    failures = sim.failures()
+    build_info = sim.ctx.build_info()
     final = sim.download()
     vmax = float(np.sqrt((final["velocities"] ** 2).sum(axis=1)).max())
     sane = bool(np.isfinite(final["points"]).all() and np.isfinite(final["velocities"]).all())
@@ -187,7 +201,24 @@ def main():
     value = args.n * args.steps / dt
     ms_search = st["ms_search"] / max(st["steps"], 1)      # HIP events on the library's stream, around the search launches
     achieved = B_SEARCH * args.n / (ms_search * 1e-3) / 1e9
-    prof = search_profile(args.n, args.k)
+    tag = workload_tag(args.workload, args.forms, args.species, args.drag)
+    prof = search_profile(tag, args.n, args.k)
+    # the a6-inclusive figure beside the core one (nsc.hydro_update always forms F[s,i], nsc:624-627; the headline's step
+    # leaves it out, as `config` says): the same workload with the species pass in the step, a short run outside the timed one
+    with_species_ms = None
+    if not args.species and state.get("f_un") is not None and os.environ.get("SPHX_BENCH_SPECIES_LINE", "1") != "0":
+        sp = Simulation(state, n_neigh=args.k, device=local_rank, gravity=args.gravity, clip_grad=args.clip_grad,
+                        forms=args.forms, d=d_loop, with_species=True, with_drag=args.drag)
+        sp.step(args.warmup, fixed_dt=fixed_dt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sp.step(10, fixed_dt=fixed_dt)
+        torch.cuda.synchronize()
+        with_species_ms = (time.perf_counter() - t1) / 10 * 1e3
+        sp.ctx.close()
+        del sp
+    ipq = prof.get("valu_wave_instr_per_query")
+    valu_achieved = (ipq * args.n / (ms_search * 1e-3) / 1e9) if ipq else None
     b_step = B_STEP_SPECIES if args.species else B_STEP_CORE
     out = {
         "metric": "particle-steps/sec + achieved HBM GB/s, 10^6-particle 3D sphere, 1/2/4/8 GPUs",
@@ -200,24 +231,41 @@ def main():
                    "particles_per_gpu": args.n, "decomposition": "single GPU",
                    "gravity": args.gravity or "off", "dt": args.dt, "cloud_size_scale": scale,
                    "forms": args.forms, "species_pass": bool(args.species), "drag": bool(args.drag),
-                   "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)"},
+                   "kernel_gradient": "clipped (physics option)" if args.clip_grad else "as nsc.hydro_update (unclipped)",
+                   # the library as built and the SPHX_* environment of this run: the configuration the parity tests ran is
+                   # "experiments=0" with no SPHX_* variable set
+                   "build": build_info,
+                   "env": {k_: v for k_, v in sorted(os.environ.items()) if k_.startswith("SPHX_")}},
+        "with_species_ms_per_step": with_species_ms,
         # the reference's scheme can diverge: evidence that the timed window was a sane flow
         "state_check": {"finite": sane, "max_speed_m_s": vmax,
-                        "max_drift_per_step_in_mean_h": vmax * float(final["dt"]) / float(final["sizes"].mean())},
+                        "max_drift_per_step_in_mean_h": vmax * float(final["dt"]) / float(final["sizes"].mean()),
+                        # the library's own failure counters over the timed steps (sphx_stats.bad_*: by ballot inside the
+                        # update kernels - what the reference's nan_to_num guards hid; no download needed)
+                        "failures": failures},
         # The dominant kernel is the search (knn_group_kernel + the list-mode knn_kernel for what it hands on).  SURVEY
         # 8(d) prices it against HBM (achieved / peak / frac below, live from this run's events); the counters say it
         # is bound by instruction issue and latency, not by HBM: `limiter` and the profiled fractions name that.
-        "roofline": {"bound": "hbm", "kernel": "search: knn_group_kernel + knn_kernel<0,1,1> (list mode)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # ONE bound named: vector-instruction issue.  achieved = wave-instructions the search's two launches issue per second
+        # (instructions per query from the committed counter profile of this build and workload x the queries of this
+        # run / the launches' time measured in THIS run with HIP events on the library's stream); peak as above; frac =
+        # achieved / peak.  The counter view of the same thing (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles at the clock the
+        # profiled run held) rides along as valu_issue_frac_counters.  The HBM pricing SURVEY 8(d) asks for - algorithmic
+        # 192 B per query against the 8 TB/s peak, and the counter traffic - is the `hbm` object: a few per cent, which is
+        # the point: this path is not memory-bound.
+        "roofline": {"bound": "valu_issue", "kernel": "search: knn_group_kernel + knn_kernel<0,1,1> (list mode)",
+                     "achieved": valu_achieved, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                     "frac": (valu_achieved / VALU_PEAK_GINSTR) if valu_achieved else None,
                      "traffic": prof.get("traffic_bytes_per_launch"),
                      "traffic_source": prof.get("source", None),
-                     "limiter": "VALU issue (instruction count) + LDS/memory latency; not HBM",
+                     "valu_issue_frac_counters": prof.get("valu_issue_frac"),
+                     "valu_wave_instr_per_query": ipq,
                      "l2_hit_rate": prof.get("l2_hit_rate"),
-                     "valu_issue_frac": prof.get("valu_issue_frac"),
-                     "valu_wave_instr_per_query": prof.get("valu_wave_instr_per_query"),
                      "profiled_counters_source": prof.get("source", None),
-                     "algorithmic_bytes_per_launch": B_SEARCH * args.n,
-                     "algorithmic_bytes_per_particle": B_SEARCH, "kernel_ms": ms_search},
+                     "kernel_ms": ms_search,
+                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": B_SEARCH * args.n, "algorithmic_bytes_per_particle": B_SEARCH,
+                             "traffic": prof.get("traffic_bytes_per_launch")}},
         "step_model": {"algorithmic_bytes_per_particle_step": b_step,
                        "achieved_GBs": b_step * value / 1e9,
                        "frac_of_hbm_peak": b_step * value / 1e9 / HBM_PEAK_GBS},

@@ -79,6 +79,13 @@ typedef struct sphx_stats {
     int64_t detail_steps;  /* steps accumulated in ms_prep .. ms_integrate, ms_gravity, ms_species (sphx_set_timing_detail) */
     int64_t far_queries;   /* last hinted search but one: queries outside the grid box with a search sphere wider than 8 cells */
     int64_t outlier_levels;/* last hinted search: nested outlier levels it was given (0: none built) */
+    /* Failure counters (particles, summed over the steps since sphx_reset_stats; 0 in a sane run).  The reference guards
+     * its loop with nan_to_num alone (sph/code_running.py:233-238, 460-463, 490-491) and carries on; so does the step -
+     * these say how often that guard was needed.  Counted on the device by ballot where the values are in registers.  */
+    int64_t bad_accel;     /* pressure / viscous / drag acceleration NaN or inf before nan_to_num (rho_i = 0 or NaN, ...)   */
+    int64_t bad_energy;    /* E or heat x dt NaN or inf before the nan_to_num of drv:490                                    */
+    int64_t bad_state;     /* updated position or velocity NaN or inf (the next step's clamp, drv:233-238, catches them)    */
+    int64_t bad_h;         /* kNN radius 0 (coincident points), NaN or inf                                                  */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */
@@ -86,6 +93,12 @@ int         sphx_create(sphx_ctx** out, int device);
 void        sphx_destroy(sphx_ctx* ctx);
 const char* sphx_last_error(const sphx_ctx* ctx);
 int         sphx_version(void);
+/* How the library was built ("gfx950 experiments=0" is the product: timing experiments and diagnostics that add
+ * launches or change results exist only in -DSPHX_EXPERIMENTS builds), and the SPHX_* environment variables a context
+ * read when it was created ("NAME=value ...": performance tunables only, read once, in sphx_create).  A benchmark line
+ * carries both, so that it can be shown to be the configuration the parity tests ran.                           */
+const char* sphx_build_info(void);
+const char* sphx_tunables(const sphx_ctx* ctx);
 /* Page-locked host memory for the big arrays the array entry points hand back ((N,K) int64 + float64 from
  * sphx_neighbors: 640 MB at N = 1e6, K = 40): device-to-host copies into it run at the link's rate instead of
  * being staged through the runtime's bounce buffers (~4x).  Any host pointer is accepted everywhere; this is
@@ -289,6 +302,11 @@ int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int first, double f
 int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, double* accel,
                         double* E_internal, double* T, double* sizes, double* rho,
                         double* nden, double* visc_heat, double* dt_last);
+/* P_i = n_i k_B T_i (n,), caller order: number density (nsc:607) and temperature of ONE instant - the one the last step's
+ * sums were formed at.  (The reference's own `pressure` line is commented out, nsc:608; north_star names P as an output.
+ * T of sphx_state_download is the UPDATED temperature, drv:491; the one the sums read is kept by the update at no cost.)
+ * Zeros before the first step.  Same caveat as rho / nden above about array calls on the same context.            */
+int sphx_state_download_pressure(sphx_ctx* ctx, double* pressure);
 int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out);
 int sphx_reset_stats(sphx_ctx* ctx);
 

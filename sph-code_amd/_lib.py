@@ -24,7 +24,8 @@ class SphxStats(C.Structure):
                                          "rebuild_steps")] + \
                [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64),
                 ("ms_species", C.c_double), ("short_rows", C.c_int64), ("detail_steps", C.c_int64), ("far_queries", C.c_int64),
-                ("outlier_levels", C.c_int64)]
+                ("outlier_levels", C.c_int64), ("bad_accel", C.c_int64), ("bad_energy", C.c_int64), ("bad_state", C.c_int64),
+                ("bad_h", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -40,6 +41,8 @@ SIGNATURES = {
     "sphx_destroy": (None, [_P]),
     "sphx_last_error": (C.c_char_p, [_P]),
     "sphx_version": (C.c_int, []),
+    "sphx_build_info": (C.c_char_p, []),
+    "sphx_tunables": (C.c_char_p, [_P]),
     "sphx_host_alloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "sphx_host_free": (C.c_int, [_P]),
     "sphx_set_constants": (C.c_int, [_P, C.POINTER(SphxConstants)]),
@@ -73,6 +76,7 @@ SIGNATURES = {
     "sphx_gravity_tree": (C.c_int, [_P, C.c_int64, _D, _D, _D, C.c_double, C.c_double, C.c_int, C.c_int, _D]),
     "sphx_step": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]),
     "sphx_state_download": (C.c_int, [_P] + [_D] * 10),
+    "sphx_state_download_pressure": (C.c_int, [_P, _D]),
     "sphx_get_stats": (C.c_int, [_P, C.POINTER(SphxStats)]),
     "sphx_reset_stats": (C.c_int, [_P]),
     "sphx_set_stream": (C.c_int, [_P, C.c_void_p]),
@@ -263,6 +267,11 @@ class Context:
 
     def reset_stats(self):
         self.check(self.lib.sphx_reset_stats(self.h))
+
+    def build_info(self):
+        """-> dict: how libsphx.so was built and which SPHX_* tunables this context read from the environment."""
+        return {"library": self.lib.sphx_build_info().decode(), "tunables": self.lib.sphx_tunables(self.h).decode(),
+                "lib_path": LIB_PATH}
 
     def set_timing_detail(self, on=True):
         """Per-pass timing events in sphx_step (ms_prep ... ms_integrate); off by default: each costs the stream ~10 us."""

@@ -2,6 +2,7 @@
 
 Every .hip source is compiled to its own object (in parallel, rebuilt only when it or a header is
 newer) and the objects are linked into sph-code_amd/libsphx.so."""
+import fcntl
 import os
 import shutil
 import subprocess
@@ -34,22 +35,32 @@ def _flag_stamp(extra):
     return " ".join(FLAGS + extra)
 
 
+def _extra_flags():
+    """SPHX_EXTRA_FLAGS, e.g. -DSPHX_EXPERIMENTS (timing experiments / diagnostics: never in the product build) or
+    -DSPHX_KNN_PROF."""
+    return os.environ.get("SPHX_EXTRA_FLAGS", "").split()
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
+    stamp_file = os.path.join(OBJ, "flags.txt")
+    if os.path.exists(stamp_file) and open(stamp_file).read() != _flag_stamp(_extra_flags()):
+        return True                      # same sources, other flags
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in _sources()] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _compile(hipcc, src, obj, extra, verbose):
-    cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj + ".tmp", src]
+    tmp = "%s.%d.tmp" % (obj, os.getpid())
+    cmd = [hipcc] + FLAGS + extra + ["-c", "-o", tmp, src]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, res.stdout, res.stderr))
-    os.replace(obj + ".tmp", obj)
+    os.replace(tmp, obj)
     return res.stderr
 
 
@@ -58,8 +69,18 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = hipcc_path()
-    extra = os.environ.get("SPHX_EXTRA_FLAGS", "").split()
     os.makedirs(OBJ, exist_ok=True)
+    # one builder at a time (ranks under torch.distributed.run, pytest-xdist workers, a variants script beside a test run);
+    # whoever waited finds the work done
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        return _build_locked(hipcc, force, verbose)
+
+
+def _build_locked(hipcc, force, verbose):
+    extra = _extra_flags()
     stamp_file = os.path.join(OBJ, "flags.txt")
     same_flags = os.path.exists(stamp_file) and open(stamp_file).read() == _flag_stamp(extra)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS)
@@ -77,13 +98,14 @@ def build(force=False, verbose=False):
             if verbose and warn.strip():
                 print(warn)
     open(stamp_file, "w").write(_flag_stamp(extra))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

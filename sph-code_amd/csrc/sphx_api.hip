@@ -47,6 +47,21 @@ static void default_constants(sphx_constants* c) {
 
 extern "C" int sphx_version(void) { return 100; }
 
+// How this library was built, and what a context read from the environment when it was created (bench.py puts both into
+// its line).  "experiments=0" is the product: no result-changing or extra-launch switches are compiled in.
+extern "C" const char* sphx_build_info(void) {
+#ifdef SPHX_EXPERIMENTS
+    return "gfx950 experiments=1"
+#else
+    return "gfx950 experiments=0"
+#endif
+#ifdef SPHX_KNN_PROF
+           " knn_prof=1"
+#endif
+        ;
+}
+extern "C" const char* sphx_tunables(const sphx_ctx* ctx) { return ctx ? ctx->tunables : ""; }
+
 extern "C" int sphx_host_alloc(void** out, size_t bytes) {
     if (!out) return SPHX_E_ARG;
     *out = nullptr;
@@ -78,42 +93,63 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     memset(&ctx->grid, 0, sizeof(ctx->grid));
     default_constants(&ctx->cst);
-    if (const char* e = getenv("SPHX_RSCALE")) { double v = atof(e); if (v >= 1.0) ctx->rscale = v; }
-    if (const char* e = getenv("SPHX_CELL")) { double v = atof(e); if (v > 0.0) ctx->cell_factor = v; }
-    if (const char* e = getenv("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
-    if (const char* e = getenv("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
-    if (const char* e = getenv("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
-    if (const char* e = getenv("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_MAX_CELLS")) ctx->max_cells = atoll(e);
-    if (const char* e = getenv("SPHX_CELL_FEEDBACK")) ctx->cell_feedback = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_CELL_FB_HI")) ctx->cell_fb_hi = atof(e);
-    if (const char* e = getenv("SPHX_CELL_FB_LO")) ctx->cell_fb_lo = atof(e);
-    if (const char* e = getenv("SPHX_DRAG_LDS")) ctx->drag_lds = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
-    if (const char* e = getenv("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
-    if (const char* e = getenv("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
-    if (const char* e = getenv("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
-    if (const char* e = getenv("SPHX_GRAV_ORDER")) { int v = atoi(e); if (v == 1 || v == 2) ctx->grav_order = v; }
-    if (const char* e = getenv("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
-    if (const char* e = getenv("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
-    if (const char* e = getenv("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
-    if (const char* e = getenv("SPHX_KNN_ABL")) ctx->exp_knn = atoi(e);
-    if (const char* e = getenv("SPHX_BLOB_EXP")) ctx->exp_blob = atoi(e);
-    if (const char* e = getenv("SPHX_BLOB_EXP_LDS")) ctx->exp_blob_lds = (size_t)atoi(e);
-    if (const char* e = getenv("SPHX_PASS_EXP")) ctx->exp_pass = atoi(e);
-    if (const char* e = getenv("SPHX_BLOB_WGS")) {      // workgroups per CU of the LDS passes' persistent grid
+    // Tunables: read from the environment ONCE, here, and recorded (sphx_tunables): a bench line can show the
+    // configuration it ran.  None of them changes a result (every variant is pinned bit for bit to the default by the
+    // tests); switches that do - timing experiments, diagnostics - exist only in -DSPHX_EXPERIMENTS builds.
+    auto env = [&](const char* name) -> const char* {
+        const char* e = getenv(name);
+        if (e) {
+            const size_t used = strlen(ctx->tunables);
+            snprintf(ctx->tunables + used, sizeof(ctx->tunables) - used, "%s%s=%s", used ? " " : "", name, e);
+        }
+        return e;
+    };
+    if (const char* e = env("SPHX_RSCALE")) { double v = atof(e); if (v >= 1.0) ctx->rscale = v; }
+    if (const char* e = env("SPHX_CELL")) { double v = atof(e); if (v > 0.0) ctx->cell_factor = v; }
+    if (const char* e = env("SPHX_RSCALE_BUILD")) { double v = atof(e); if (v >= 1.0) ctx->rscale_build = v; }
+    if (const char* e = env("SPHX_VERLET")) ctx->use_verlet = atoi(e) != 0;
+    if (const char* e = env("SPHX_BLOB")) ctx->use_blob = atoi(e) != 0;
+    if (const char* e = env("SPHX_BLOB_CURVE")) ctx->blob_curve = atoi(e);
+    if (const char* e = env("SPHX_KNN_GROUP")) ctx->use_group = atoi(e) != 0;
+    if (const char* e = env("SPHX_HCLIP")) { double v = atof(e); if (v > 1.0) ctx->h_clip_factor = v; }
+    if (const char* e = env("SPHX_TIMING_DETAIL")) ctx->timing_detail = atoi(e) != 0;
+    if (const char* e = env("SPHX_MAX_CELLS")) ctx->max_cells = atoll(e);
+#ifndef SPHX_EXPERIMENTS
+    if (ctx->max_cells < 0) ctx->max_cells = 0;      // (lifting the limit is an experiment)
+#endif
+    if (const char* e = env("SPHX_CELL_FEEDBACK")) ctx->cell_feedback = atoi(e) != 0;
+    if (const char* e = env("SPHX_CELL_FB_HI")) ctx->cell_fb_hi = atof(e);
+    if (const char* e = env("SPHX_CELL_FB_LO")) ctx->cell_fb_lo = atof(e);
+    if (const char* e = env("SPHX_DRAG_LDS")) ctx->drag_lds = atoi(e) != 0;
+    if (const char* e = env("SPHX_SPLIT_PERM")) ctx->split_perm = atoi(e) != 0;
+    if (const char* e = env("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
+    if (const char* e = env("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
+    if (const char* e = env("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
+    if (const char* e = env("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
+    if (const char* e = env("SPHX_OUTLIER_LEVELS")) ctx->olev_mode = atoi(e);     // 0 off, 1 always, 2 when far queries were met
+    if (const char* e = env("SPHX_FUSE_COUNT")) ctx->fuse_count = atoi(e) != 0;
+    if (const char* e = env("SPHX_BOX_SIGMAS")) { double v = atof(e); if (v >= 1.0) ctx->box_sigmas = v; }
+    if (const char* e = env("SPHX_GRAV_KERNEL")) ctx->grav_per_thread = atoi(e) == 0;
+    if (const char* e = env("SPHX_GRAV_ORDER")) { int v = atoi(e); if (v == 1 || v == 2) ctx->grav_order = v; }
+    if (const char* e = env("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
+    if (const char* e = env("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
+    if (const char* e = env("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
+    if (const char* e = env("SPHX_BLOB_WGS")) {      // workgroups per CU of the LDS passes' persistent grid
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         if (atoi(e) > 0) ctx->blob_grid = ((cus * atoi(e) + 7) / 8) * 8;
     }
+#ifdef SPHX_EXPERIMENTS
+    // timing experiments and diagnostics: extra discarded launches, cut-down kernels, counters printed to stderr
+    if (const char* e = env("SPHX_KNN_ABL")) ctx->exp_knn = atoi(e);
+    if (const char* e = env("SPHX_BLOB_EXP")) ctx->exp_blob = atoi(e);
+    if (const char* e = env("SPHX_BLOB_EXP_LDS")) ctx->exp_blob_lds = (size_t)atoi(e);
+    if (const char* e = env("SPHX_PASS_EXP")) ctx->exp_pass = atoi(e);
+    ctx->exp_no_agb = env("SPHX_EXP_NO_AGB") != nullptr;
+    ctx->knn_prof_print = env("SPHX_KNN_PROF") != nullptr;
+    ctx->kg_debug_print = env("SPHX_KG_DEBUG") != nullptr;
+    (void)env("SPHX_KG_EXP_NOAMB"); (void)env("SPHX_KG_PROF");       // (read where they act, sphx_knn_group.hip; recorded here)
+#endif
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
@@ -163,7 +199,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split};
+                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->Tprev};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -762,7 +798,10 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
     ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
     ctx->stats.short_rows = (int64_t)sc[SC_SHORT];
-    if (getenv("SPHX_KNN_PROF")) {
+    ctx->stats.bad_accel = (int64_t)sc[SC_BAD_ACCEL]; ctx->stats.bad_energy = (int64_t)sc[SC_BAD_ENERGY];
+    ctx->stats.bad_state = (int64_t)sc[SC_BAD_STATE]; ctx->stats.bad_h = (int64_t)sc[SC_BAD_H];
+#ifdef SPHX_EXPERIMENTS
+    if (ctx->knn_prof_print) {
         const char* nm[4] = {"in-box", "-", "outside the box", "-"};
         for (int c = 0; c < 4; c += 2)          // (the odd slots: cycles by section of the same two classes, below)
             if (sc[SC_KNNPROF + 4 + c])
@@ -781,10 +820,11 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
                     ctx->grid.cell, ctx->grid.nx, ctx->grid.ny, ctx->grid.nz);
         HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_KNNPROF, 0, 24 * sizeof(u64), ctx->stream));
     }
-    if (getenv("SPHX_KG_DEBUG"))
+    if (ctx->kg_debug_print)
         fprintf(stderr, "[sphx] grouped search, handed on (cumulative): no-hint %llu tile %llu tol %llu >64 %llu <K %llu near-tie %llu | groups over the row cap %llu, over the pre-cull cap %llu\n",
                 sc[SC_KGDBG + 1], sc[SC_KGDBG + 2], sc[SC_KGDBG + 3], sc[SC_KGDBG + 4], sc[SC_KGDBG + 5], sc[SC_KGDBG + 6],
                 sc[SC_KGDBG + 7], sc[SC_KGDBG + 0]);
+#endif
     return SPHX_OK;
 }
 
@@ -932,6 +972,14 @@ extern "C" int sphx_state_download_species(sphx_ctx* ctx, double* F, double* Z, 
 extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
     if (!ctx || !out) return SPHX_E_ARG;
     SPHX_TRY(sphx_dev_collect(ctx));
+    if (ctx->map_perm) {               // the device-pointer API has no sphx_step to read the failure counters back: here
+        HIPCHK(hipSetDevice(ctx->device));
+        u64* hb = (u64*)((char*)ctx->pinned + 3584);
+        HIPCHK(hipMemcpyAsync(hb, ctx->scal.as<u64>() + SC_BAD_ACCEL, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->stats.bad_accel = (int64_t)hb[0]; ctx->stats.bad_energy = (int64_t)hb[1];
+        ctx->stats.bad_state = (int64_t)hb[2]; ctx->stats.bad_h = (int64_t)hb[3];
+    }
     *out = ctx->stats;
     return SPHX_OK;
 }
@@ -947,6 +995,7 @@ extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_CAND, 0, 2 * sizeof(u64), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_SHORT, 0, sizeof(u64), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_BAD_ACCEL, 0, 4 * sizeof(u64), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }

@@ -937,12 +937,14 @@ static int blob_attr_once(sphx_ctx* ctx) {
     if (ctx->blob_attr_set) return SPHX_OK;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+#ifdef SPHX_EXPERIMENTS
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_kernel<3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_pi_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(72, SPHX_MAX_K)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_visc_kernel),
@@ -955,6 +957,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(blob_attr_once(ctx));
     const int64_t npad = sphx_pad64(n);
     const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+#ifdef SPHX_EXPERIMENTS
     if (ctx->exp_blob) {        // timing experiments (SPHX_BLOB_EXP), outputs discarded
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
         double* d = ctx->in_j.as<double>();
@@ -982,6 +985,7 @@ int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k) {
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         }
     }
+#endif
     hipLaunchKernelGGL(blob_density_kernel<0>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, (int)n, (int)npad, k, nblk, ctx->clip_grad,
                        ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(),
                        ctx->qorder, ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n, ctx->rec1.as<RecA>(),

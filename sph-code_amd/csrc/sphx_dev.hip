@@ -268,6 +268,7 @@ struct DevIntegArgs {
     double* dt_out;
     int first;
     double fixed_dt, dt_0, max_age;
+    u64* counters;                // failure counters (SC_BAD_*)
 };
 __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,19 +287,26 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     }
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     double v[3], pa[3], vis[3];
+    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, SC_BAD_ACCEL)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         v[c] = a.vel[3 * (size_t)i + c];
         if (a.G) {                                            // the loop forms carry the physical sign themselves
-            pa[c] = nan_to_num_v(a.G[3 * (size_t)i + c] / a.rho[i] * g);     // drv:460
+            const double praw = a.G[3 * (size_t)i + c] / a.rho[i] * g;
+            pa[c] = nan_to_num_v(praw);                                      // drv:460
             vis[c] = a.va[3 * (size_t)i + c];                                // av[0], drv:473
+            bad_acc = bad_acc || !sphx_finite(praw) || !sphx_finite(vis[c]);
         } else {
-            pa[c] = nan_to_num_v(-a.ha[3 * (size_t)i + c] * g);
-            vis[c] = nan_to_num_v(-a.va[3 * (size_t)i + c] * g);
+            const double praw = -a.ha[3 * (size_t)i + c] * g, vraw = -a.va[3 * (size_t)i + c] * g;
+            pa[c] = nan_to_num_v(praw);
+            vis[c] = nan_to_num_v(vraw);
+            bad_acc = bad_acc || !sphx_finite(praw) || !sphx_finite(vraw);
         }
         if (a.drag_on) {                                      // drv:462-463,473
-            const double dg = nan_to_num_v(a.drag_on[3 * (size_t)i + c] * a.drhod[i] / a.drho[i] * g);
-            vis[c] = dg + nan_to_num_v(a.drag_re[3 * (size_t)i + c]) + vis[c];
+            const double draw = a.drag_on[3 * (size_t)i + c] * a.drhod[i] / a.drho[i] * g, rraw = a.drag_re[3 * (size_t)i + c];
+            const double dg = nan_to_num_v(draw);
+            vis[c] = dg + nan_to_num_v(rraw) + vis[c];
+            bad_acc = bad_acc || !sphx_finite(draw) || !sphx_finite(rraw);
         }
     }
     double x[3], old[3], tot[3];
@@ -312,9 +320,19 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
         a.acc[3 * (size_t)i + c] = tot[c];
     }
     double E = a.E[i], T;
-    sphx_energy_update(dt, a.vh[i], a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
+    const double heat = a.vh[i];
+    const bool bad_en = !sphx_finite(E) || !sphx_finite(heat * dt);
+    sphx_energy_update(dt, heat, a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
     a.E[i] = E;
     a.T[i] = T;
+    if (a.counters) {
+        bool bad_st = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bad_st = bad_st || !sphx_finite(x[c]) || !sphx_finite(v[c]);
+        sphx_count_bad(a.counters, SC_BAD_ACCEL, bad_acc);
+        sphx_count_bad(a.counters, SC_BAD_ENERGY, bad_en);
+        sphx_count_bad(a.counters, SC_BAD_STATE, bad_st);
+    }
 }
 // the drag terms handed over by sphx_dev_set_drag_terms are consumed by the next update
 static void take_drag_terms(sphx_ctx* ctx, DevIntegArgs& a) {
@@ -358,6 +376,7 @@ extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, d
     take_drag_terms(ctx, a);
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
+    a.counters = ctx->scal.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -387,6 +406,7 @@ extern "C" int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* p
     a.dt = 0.0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
+    a.counters = ctx->scal.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -415,6 +435,7 @@ extern "C" int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* p
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
+    a.counters = ctx->scal.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -655,8 +676,9 @@ __global__ __launch_bounds__(256) void need_map_kernel(long long n, const double
                                                        unsigned char* out, int rwide, u64* wide0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double wi = w[i];
-    if (!(wi > 0.0)) return;                       // claims nothing (NaN included)
+    double wi = w[i];
+    if (wi != wi) wi = INFINITY;                   // a NaN reach (a broken radius) claims everything: never a missing ghost
+    if (!(wi > 0.0)) return;                       // claims nothing
     const double g1 = (double)(G - 1);
     // the particle's own cell: floor + clamp, as torch.floor(...).clamp_(0, G - 1) does
     const double tx = fmin(fmax(floor((pos[3 * i] - lx) / cs), 0.0), g1);

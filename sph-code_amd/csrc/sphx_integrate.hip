@@ -139,13 +139,20 @@ int sphx_permute_state(sphx_ctx* ctx, int64_t n, bool split, hipEvent_t after_fi
 // No pre-zeroed accumulators: every block leaves its partial sums, the last one to finish (a ticket
 // that wraps back to 0 by itself) adds them up in block order - one launch, and the same bits every run.
 __global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, double clip, double* partial,
-                                                   unsigned* ticket, double* out_sum, double* out_cnt) {
+                                                   unsigned* ticket, double* out_sum, double* out_cnt, u64* counters) {
     __shared__ double sm[4], sc[4];
     __shared__ bool last;
     double s = 0.0, c = 0.0;
+    unsigned nbad = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double v = h[i];
         if (v > 0.0 && (clip <= 0.0 || v <= clip)) { s += v; c += 1.0; }
+        nbad += (v > 0.0 && v <= DBL_MAX) ? 0u : 1u;           // 0 (coincident points), NaN, inf: SC_BAD_H
+    }
+    if (__ballot(nbad != 0u)) {                               // (never in a sane run)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nbad += __shfl_xor(nbad, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[SC_BAD_H], (u64)nbad);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
@@ -188,7 +195,7 @@ int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > HSUM_BLOCKS) blocks = HSUM_BLOCKS;
     hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, ctx->h_clip, partial, ticket,
-                       out, cnt);
+                       out, cnt, ctx->scal.as<u64>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -243,6 +250,7 @@ struct IntegArgs {
     double* dt_out;
     int first;
     double fixed_dt, dt_0, max_age;
+    u64* counters;                                     // failure counters (SC_BAD_*); nullptr: not counted
 };
 __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,18 +271,25 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     const double v[3] = {a.vx[i], a.vy[i], a.vz[i]};
     double pa[3], vis[3];
+    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, SC_BAD_ACCEL)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (a.G) {                                            // loop forms carry the physical sign themselves
-            pa[c] = nan_to_num(a.G[3 * (size_t)i + c] / a.rho[i] * g);      // drv:460
+            const double praw = a.G[3 * (size_t)i + c] / a.rho[i] * g;
+            pa[c] = nan_to_num(praw);                                       // drv:460
             vis[c] = a.va[3 * (size_t)i + c];                               // av[0], drv:473
+            bad_acc = bad_acc || !sphx_finite(praw) || !sphx_finite(vis[c]);
         } else {
-            pa[c] = nan_to_num(-a.ha[3 * (size_t)i + c] * g);     // physical sign, drv:460
-            vis[c] = nan_to_num(-a.va[3 * (size_t)i + c] * g);
+            const double praw = -a.ha[3 * (size_t)i + c] * g, vraw = -a.va[3 * (size_t)i + c] * g;
+            pa[c] = nan_to_num(praw);                             // physical sign, drv:460
+            vis[c] = nan_to_num(vraw);
+            bad_acc = bad_acc || !sphx_finite(praw) || !sphx_finite(vraw);
         }
         if (a.drag_on) {                                      // drv:462-463,473
-            const double dg = nan_to_num(a.drag_on[3 * (size_t)i + c] * a.rhod[i] / a.rho[i] * g);
-            vis[c] = dg + nan_to_num(a.drag_re[3 * (size_t)i + c]) + vis[c];
+            const double draw = a.drag_on[3 * (size_t)i + c] * a.rhod[i] / a.rho[i] * g, rraw = a.drag_re[3 * (size_t)i + c];
+            const double dg = nan_to_num(draw);
+            vis[c] = dg + nan_to_num(rraw) + vis[c];
+            bad_acc = bad_acc || !sphx_finite(draw) || !sphx_finite(rraw);
         }
     }
     double x[3] = {a.x[i], a.y[i], a.z[i]};
@@ -288,9 +303,19 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     a.vx[i] = vv[0]; a.vy[i] = vv[1]; a.vz[i] = vv[2];
     a.ax[i] = tot[0]; a.ay[i] = tot[1]; a.az[i] = tot[2];
     double E = a.E[i], T;
-    sphx_energy_update(dt, a.vh[i], a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
+    const double heat = a.vh[i];
+    const bool bad_en = !sphx_finite(E) || !sphx_finite(heat * dt);
+    sphx_energy_update(dt, heat, a.mu[i], a.gam[i], a.m[i], a.m_h, a.kB, E, T);   // drv:490-491
     a.E[i] = E;
     a.T[i] = T;
+    if (a.counters) {
+        bool bad_st = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bad_st = bad_st || !sphx_finite(x[c]) || !sphx_finite(vv[c]);
+        sphx_count_bad(a.counters, SC_BAD_ACCEL, bad_acc);
+        sphx_count_bad(a.counters, SC_BAD_ENERGY, bad_en);
+        sphx_count_bad(a.counters, SC_BAD_STATE, bad_st);
+    }
 }
 
 int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixed_dt) {
@@ -303,7 +328,8 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixe
     a.x = s.x.as<double>(); a.y = s.y.as<double>(); a.z = s.z.as<double>();
     a.vx = s.vx.as<double>(); a.vy = s.vy.as<double>(); a.vz = s.vz.as<double>();
     a.ax = s.ax.as<double>(); a.ay = s.ay.as<double>(); a.az = s.az.as<double>();
-    a.E = s.E.as<double>(); a.T = s.T.as<double>();
+    SPHX_TRY(sphx_ensure(ctx, ctx->Tprev, (size_t)n * sizeof(double)));
+    a.E = s.E.as<double>(); a.T = ctx->Tprev.as<double>();      // (the kernel never reads T: written elsewhere, swapped below)
     a.m = s.m.as<double>(); a.mu = s.mu.as<double>(); a.gam = s.gam.as<double>();
     a.ptype = s.ptype.as<double>();
     a.ha = ctx->ha.as<double>(); a.va = ctx->va.as<double>(); a.vh = ctx->vh.as<double>();
@@ -315,8 +341,32 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixe
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     a.no_old = 0;
+    a.counters = ctx->scal.as<u64>();
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
+    { DevBuf t = s.T; s.T = ctx->Tprev; ctx->Tprev = t; }       // st.T: the new temperatures; Tprev: those the sums read
+    return SPHX_OK;
+}
+
+// P_i = n_i k_B T_i with n and T of the same instant - the one the step's sums were formed at (nsc:607; the reference's
+// own `pressure` line is commented out at nsc:608) - scattered into the caller's order
+__global__ __launch_bounds__(256) void pressure_by_id(int n, const int* id, const double* nden, const double* T, double kB,
+                                                      double* out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[id[t]] = nden[t] * kB * T[t];
+}
+extern "C" int sphx_state_download_pressure(sphx_ctx* ctx, double* pressure) {
+    if (!ctx || !pressure) return SPHX_E_ARG;
+    if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "no state uploaded");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = ctx->n;
+    if (ctx->step_count < 1 || !ctx->Tprev.p) { memset(pressure, 0, (size_t)n * sizeof(double)); return SPHX_OK; }
+    SPHX_TRY(sphx_ensure(ctx, ctx->out_a, (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(pressure_by_id, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
+                       ctx->st.id.as<int>(), ctx->nden.as<double>(), ctx->Tprev.as<double>(), ctx->cst.k_B, ctx->out_a.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(pressure, ctx->out_a.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }
 
@@ -433,6 +483,7 @@ extern "C" int sphx_leapfrog(sphx_ctx* ctx, int64_t n, double* points, double* v
     a.dt = dtd;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     a.no_old = old_accel ? 0 : 1;
+    a.counters = nullptr;              // (an array call on the caller's arrays: its NaNs are the caller's to see)
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     struct Out { double* host; double *a, *b, *c; } outs[] = {{points, x, y, z}, {velocities, vx, vy, vz}, {total_accel, ax, ay, az}};

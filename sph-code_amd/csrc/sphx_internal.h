@@ -284,6 +284,10 @@ struct sphx_ctx {
     DevBuf idx64, dist_out, nontriv, h_api;
     // ---- simulation state ----
     StateArrays st, alt;
+    // The update writes the new temperatures into this buffer and swaps it with st.T: what is left here is T at the instant
+    // of the step's sums, in the step's sorted order like rho / nden - P_i = n_i k_B T_i of ONE instant at no cost to the
+    // step (sphx_state_download_pressure)
+    DevBuf Tprev;
     bool has_state = false;
     int64_t step_count = 0;
     double dt_last = 0.0;
@@ -304,8 +308,10 @@ struct sphx_ctx {
     bool ct_primed = false;             // SC_CT_BITS holds "none yet" (left so by dt_kernel)
     DevBuf scal_tmp;                    // step_scalars_kernel's per-block partials + its ticket
     DevBuf hsum_tmp;                    // hsum_kernel's per-block partial sums + its ticket
-    int exp_knn = -1, exp_blob = 0, exp_pass = -1;
+    int exp_knn = -1, exp_blob = 0, exp_pass = -1;      // (-DSPHX_EXPERIMENTS builds only: never set otherwise)
     size_t exp_blob_lds = 0;
+    bool exp_no_agb = false, knn_prof_print = false, kg_debug_print = false;
+    char tunables[1024] = {0};          // "NAME=value ..." of every SPHX_* variable sphx_create read (sphx_tunables)
     hipEvent_t evring[3][10] = {{nullptr}};
     bool timing_detail = false;         // per-pass timing events in sphx_step (sphx_set_timing_detail)
     bool ev_detail[3] = {false, false, false};
@@ -383,7 +389,14 @@ enum {
     SC_DENSEP = 14,   // u64, only grows: particles in cells of >= DENSE_CELL members (a tile's 27 such cells overflow it)
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
     SC_KNNPROF = 24,  // u64[16]: general search, cycles / queries / longest / tries by query class (-DSPHX_KNN_PROF builds)
-    SC_NSLOTS = 48
+    // failure counters (the reference's only guard is the nan_to_num of drv:233-238, 460-463, 490-491), all
+    // u64 and only growing, counted by ballot where the values are in registers anyway - one atomic per wave that saw any:
+    SC_BAD_ACCEL = 48,   // particles whose pressure / viscous / drag acceleration was NaN or inf before drv:460-463's nan_to_num
+                         // (rho_i = 0 or NaN: a gas particle whose list holds no gas neighbour inside its kernel)
+    SC_BAD_ENERGY = 49,  // particles whose E or heat x dt was NaN or inf before drv:490's nan_to_num
+    SC_BAD_STATE = 50,   // particles whose updated position or velocity is NaN or inf (the next step's clamp will zero / clamp them)
+    SC_BAD_H = 51,       // particles whose kNN radius came out 0 (coincident points), NaN or inf
+    SC_NSLOTS = 56
 };
 
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------

@@ -739,6 +739,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.h_by_id = out.h_by_id;
     a.counters = ctx->scal.as<u64>();
     int blocks = (int)(sphx_pad64(n) / KNN_PPB);
+#ifdef SPHX_EXPERIMENTS
     if (ctx->exp_knn >= 0) {       // timing experiment (SPHX_KNN_ABL), results discarded
         KnnArgs b = a;
         b.nbr = nullptr; b.list64 = nullptr; b.dref = nullptr; b.h_sorted = nullptr; b.idx64 = nullptr; b.dist = nullptr; b.nontriv = nullptr;
@@ -760,6 +761,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         fprintf(stderr, "[sphx] knn ablation %d: %.4f ms\n", mode, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+#endif
     a.qlist = nullptr; a.qcount = nullptr;
     a.distrust = 0;
     a.ol.L = 0; a.ol.start = nullptr; a.ol.list = nullptr; a.ol.cx = a.ol.cy = a.ol.cz = 0.0; a.ol.hmax = 1.0;

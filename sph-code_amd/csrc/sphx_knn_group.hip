@@ -368,13 +368,19 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
                 }
             }
             // the word's set bits -> the query's slot list (candidates entered at bit 0 and moved up: first = highest);
-            // the four waves append through the query's counter (the order of a list does not matter: it is sorted)
-            while (__builtin_amdgcn_ballot_w64(m != 0u)) {
-                if (m != 0u) {
-                    const int j = __clz((int)m);
-                    m &= ~(0x80000000u >> j);
-                    const int slot = atomicAdd(&cntq[lane], 1);
-                    if (slot < 64) slist[slot * 64 + lane] = (unsigned short)(w * 32 + j);
+            // the four waves append through the query's counter (the order of a list does not matter: it is sorted).
+            // ONE reservation per lane and word (a returning LDS atomic is a round trip; in the loop - one per set bit -
+            // it was a chain of up to seven per word for the wave's busiest lane), then plain stores.
+            if (__builtin_amdgcn_ballot_w64(m != 0u)) {
+                int slot = 0;
+                if (m != 0u) slot = atomicAdd(&cntq[lane], __popc(m));
+                while (__builtin_amdgcn_ballot_w64(m != 0u)) {
+                    if (m != 0u) {
+                        const int j = __clz((int)m);
+                        m &= ~(0x80000000u >> j);
+                        if (slot < 64) slist[slot * 64 + lane] = (unsigned short)(w * 32 + j);
+                        ++slot;
+                    }
                 }
             }
         }
@@ -535,7 +541,10 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         am |= __builtin_amdgcn_update_dpp(0, am, 0xB1, 0xF, 0xF, true);
         am |= __builtin_amdgcn_update_dpp(0, am, 0x4E, 0xF, 0xF, true);
         if (okq && (am & 2)) { okq = false; failq = true; q_why = 5; }
-        if (okq && (am & 1) && !a.exp_noamb) { okq = false; failq = true; q_why = 6; }
+        #ifdef SPHX_EXPERIMENTS
+        if (a.exp_noamb) am &= ~1;
+#endif
+        if (okq && (am & 1)) { okq = false; failq = true; q_why = 6; }
     }
     KG_STAMP(5)
     // ---- outputs: rank r = 16 part + u ----
@@ -590,9 +599,14 @@ int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a0) {
     KnnGroupArgs a = a0;
     const int blocks = a.npad / 64;
     a.prof = nullptr;
+#ifdef SPHX_EXPERIMENTS
     static const bool noamb = getenv("SPHX_KG_EXP_NOAMB") != nullptr;     // timing experiment only: near ties NOT handed on (wrong results)
     a.exp_noamb = noamb ? 1 : 0;
     static const bool prof = getenv("SPHX_KG_PROF") != nullptr;
+#else
+    a.exp_noamb = 0;
+    const bool prof = false;
+#endif
     if (prof) {           // diagnostic: per-section shader cycles of one launch (summed over the waves' lane 0)
         SPHX_TRY(sphx_ensure(ctx, ctx->scal_tmp, 4096));
         u64* pd = ctx->scal_tmp.as<u64>() + 256;

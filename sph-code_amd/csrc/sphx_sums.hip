@@ -206,6 +206,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
     SPHX_TRY(sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double)));
     SPHX_TRY(sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double)));
     if (ctx->qorder && ctx->blob_lists) return sphx_blob_density(ctx, n, k);
+#ifdef SPHX_EXPERIMENTS
     if (ctx->exp_pass >= 0) {        // timing experiment (SPHX_PASS_EXP), outputs discarded
         const int mode = ctx->exp_pass;
         SPHX_TRY(sphx_ensure(ctx, ctx->in_j, (size_t)n * 12 * sizeof(double)));
@@ -228,6 +229,7 @@ int sphx_pass_density(sphx_ctx* ctx, int64_t n, int k) {
         fprintf(stderr, "[sphx] pass_density experiment %d: %.4f ms\n", mode, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+#endif
     hipLaunchKernelGGL(pass_density_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (int)n, (int)sphx_pad64(n), k, ctx->clip_grad, ctx->nbr.as<int>(), ctx->rec1.as<RecA>(),
                        ctx->rho_s.as<double>(), ctx->qorder, OutMap{ctx->map_perm, ctx->map_perm ? ctx->map_nactive : (int)n},
@@ -744,7 +746,9 @@ __global__ __launch_bounds__(256) void step_species_kernel(int n, int npad, int 
 int sphx_species_on(sphx_ctx* ctx, int64_t n, int k, int S, int SP, const double* fun, const int* row_of, const double* m_sorted,
                     double* F, double* Z, double* agb) {
     int agb_on = (ctx->agb_on && Z && agb) ? 1 : 0;
-    if (getenv("SPHX_EXP_NO_AGB")) agb_on = 0;          // timing experiment: the species sums alone
+#ifdef SPHX_EXPERIMENTS
+    if (ctx->exp_no_agb) agb_on = 0;          // timing experiment (SPHX_EXP_NO_AGB): the species sums alone
+#endif
     // out of LDS when the step's blob lists are at hand (sphx_blob.hip); the gather form below otherwise
     if (ctx->use_lds && ctx->blob_lists && ctx->qorder && SP == 16 && S <= 16 && k <= SPHX_MAX_K && ctx->species_lds)
         return sphx_blob_species(ctx, n, k, S, fun, row_of, m_sorted, F, Z, agb, agb_on);

@@ -107,10 +107,15 @@ def sedov_sphere(n, seed=12348, radius=0.625e6 * AU, energy=1e44, kick_mass=194.
     return st
 
 
-def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000., light=False, size_scale=1.0):
-    """C4: the reference's own IC (sph/code_running.py:62,132)."""
+def uniform_cube(n, seed=12349, side=1.25e6 * AU, sigma_v=1000., light=False, size_scale=1.0, box=None):
+    """C4: the reference's own IC (sph/code_running.py:62,132).  box = (lo, hi): the n particles fill that part of the
+    cube instead (one rank's brick of a decomposed run, seeded per brick: ics.cube_slab)."""
     rs = np.random.RandomState(seed)
-    pts = (rs.rand(n, 3) - 0.5) * (side * size_scale)
+    if box is not None:
+        blo, bhi = np.asarray(box[0], dtype=np.float64), np.asarray(box[1], dtype=np.float64)
+        pts = blo[None, :] + rs.rand(n, 3) * (bhi - blo)[None, :]
+    else:
+        pts = (rs.rand(n, 3) - 0.5) * (side * size_scale)
     mass = np.full(n, 0.4 * SOLAR / 715.)
     T = 10. * (1. + rs.rand(n))
     vel = rs.normal(size=(n, 3)) * sigma_v
@@ -166,6 +171,18 @@ def dusty_sphere(n, seed=12350, dust_frac=0.05, **kw):
     mass[dust] = DUST_MASS
     f_un = np.where((ptype == 2.)[:, None], F_DUST[None, :], F_GAS[None, :])
     return _finish(s["points"], s["velocities"], mass, s["T"], ptype=ptype, f_un=f_un)
+
+
+def cube_slab(workload, n_rank, rank, box_lo, box_hi, light=False):
+    """One rank's share of a decomposed uniform_cube / two_phase run WITHOUT building the global state on every rank: n_rank
+    particles uniform in the rank's own brick (multigpu.brick_regions), every other field drawn as the global IC draws it,
+    the stream seeded by (workload seed, rank).  The union over the ranks is a uniform fill of the cube with exactly
+    world x n_rank particles - the same ensemble as WORKLOADS[workload](world * n_rank), not the same sample."""
+    if workload == "uniform_cube":
+        return uniform_cube(n_rank, seed=12349 + 1000 * (rank + 1), light=light, box=(box_lo, box_hi))
+    if workload == "two_phase":
+        return two_phase(n_rank, seed=12351 + 1000 * (rank + 1), box=(box_lo, box_hi))
+    raise ValueError("cube_slab: %s does not fill a box" % workload)
 
 
 def two_phase(n, seed=12351, dust_frac=0.10, **kw):

@@ -80,6 +80,33 @@ def rcb_regions(points, world):
     return owner, lo, hi
 
 
+def brick_regions(world, box_lo, box_hi):
+    """The regions rcb_regions would cut a UNIFORM fill of the box [box_lo, box_hi] into, without the particles: recursive
+    bisection of the box along its longest edge, volumes in proportion to the ranks on each side.  -> (lo, hi) (world,3)
+    with the outer faces at -inf / +inf like rcb_regions', and the finite boxes (blo, bhi) to fill."""
+    lo = np.full((world, 3), -np.inf); hi = np.full((world, 3), np.inf)
+    flo = np.zeros((world, 3)); fhi = np.zeros((world, 3))
+
+    def split(r0, r1, blo, bhi, glo, ghi):
+        nr = r1 - r0
+        if nr == 1:
+            lo[r0], hi[r0], flo[r0], fhi[r0] = glo, ghi, blo, bhi
+            return
+        nl = nr // 2
+        ax = int(np.argmax(bhi - blo))
+        cut = blo[ax] + (bhi[ax] - blo[ax]) * nl / nr
+        lhi, rlo = np.array(bhi), np.array(blo)
+        lhi[ax] = cut; rlo[ax] = cut
+        glhi, grlo = np.array(ghi), np.array(glo)
+        glhi[ax] = cut; grlo[ax] = cut
+        split(r0, r0 + nl, np.array(blo), lhi, np.array(glo), glhi)
+        split(r0 + nl, r1, rlo, np.array(bhi), grlo, np.array(ghi))
+
+    split(0, world, np.asarray(box_lo, dtype=np.float64), np.asarray(box_hi, dtype=np.float64),
+          np.full(3, -np.inf), np.full(3, np.inf))
+    return lo, hi, flo, fhi
+
+
 def region_of(pos, lo, hi):
     """Owner rank of each position (torch (n,3)); regions tile space, ties go to the lower rank."""
     inside = ((pos[:, None, :] >= lo[None]) & (pos[:, None, :] <= hi[None])).all(dim=2)   # (n, world)
@@ -479,6 +506,7 @@ class DistributedSim:
     owned particles (reference array conventions, sph/code_running.py:114-177) plus 'gid'
     (global particle ids); `lo`/`hi` are the (world,3) region boxes of rcb_regions."""
 
+    phase = "setup"                              # the section of step() this process is in (class-wide: one sim per process)
     DT_0 = 60. * 60. * 24. * 365. * 250000.      # nsc:38
     MAX_AGE = 3e7 * 60. * 60. * 24. * 365.       # drv:79
 
@@ -498,7 +526,8 @@ class DistributedSim:
         # (the reverse halo).  with_species: every step forms f_un_neighbor (nsc:624-627) for the owned particles (ghosts
         # carry their composition rows); agb = (splines, mapto, divisor): also the metallicity and the AGB yields.
         self.with_drag, self.with_species, self.agb = bool(with_drag), bool(with_species or agb is not None), agb
-        if (self.with_drag or self.with_species) and state.get("f_un") is None:
+        drag_given = state.get("mean_grain_mass") is not None and state.get("mean_cross_section") is not None
+        if (self.with_species or (self.with_drag and not drag_given)) and state.get("f_un") is None:
             raise ValueError("with_drag / with_species need a state with f_un")
         self.rank, self.world, self.backend = rank, world, backend
         self.device = torch.device(device)
@@ -516,10 +545,13 @@ class DistributedSim:
         self.s["gid"] = torch.as_tensor(np.asarray(state["gid"], dtype=np.int64)).to(self.device)
         self.extra_fields = []                  # per-particle fields beyond the core set: migrate and travel as ghosts
         if self.with_drag:
-            from . import compat
-            fu = np.asarray(state["f_un"], dtype=np.float64)
-            self.s["mgm"] = f(np.sum(compat.grain_mass() * fu, axis=1))          # nsc:725
-            self.s["mcs"] = f(np.sum(compat.sigma_effective() * fu, axis=1))     # nsc:726
+            if drag_given:                      # (a snapshot: the per-particle means as the run carried them)
+                self.s["mgm"], self.s["mcs"] = f(state["mean_grain_mass"]), f(state["mean_cross_section"])
+            else:
+                from . import compat
+                fu = np.asarray(state["f_un"], dtype=np.float64)
+                self.s["mgm"] = f(np.sum(compat.grain_mass() * fu, axis=1))          # nsc:725
+                self.s["mcs"] = f(np.sum(compat.sigma_effective() * fu, axis=1))     # nsc:726
             self.extra_fields += ["mgm", "mcs"]
         if self.with_species:
             self.s["fun"] = f(state["f_un"])
@@ -582,6 +614,7 @@ class DistributedSim:
             self.acc, self.name = acc, name
 
         def __enter__(self):
+            DistributedSim.phase = self.name             # (what a failing rank names when it gives up: bench_main)
             self.t = time.perf_counter()
 
         def __exit__(self, *exc):
@@ -627,6 +660,8 @@ class DistributedSim:
         a sphere of cells (distances under-estimated by one cell per axis), not the cube around it - the wide claims of
         rim particles would otherwise pull in the dense cloud at the cube's corners."""
         G, cs = self.G, self.g_cs
+        # (a NaN reach - a broken radius - claims everything, in both forms: as a NaN it would drop out of the kernel's
+        #  comparisons and, in the form below, swallow its cell's genuine claims in the running maximum)
         if hasattr(self.backend, "need_map"):          # fused: one launch, no host synchronisation
             return self.backend.need_map(self.s["pos"], w_owned, self.g_lo_host, cs, G)
         # the tensor-library form (the specification: what the CPU tests run, what the kernel is tested against).  The
@@ -636,6 +671,7 @@ class DistributedSim:
         out = torch.zeros(G * G * G, dtype=torch.uint8, device=dev)
         if not w_owned.numel():
             return out
+        w_owned = torch.nan_to_num(w_owned, nan=float("inf"), posinf=float("inf"), neginf=0.0)
         wmax = torch.zeros(G * G * G, dtype=torch.float64, device=dev)
         wmax.scatter_reduce_(0, self._coarse_cell(self.s["pos"]), w_owned, reduce="amax", include_self=True)
         occ = torch.nonzero(wmax > 0).flatten()
@@ -1188,19 +1224,37 @@ class DistributedSim:
                    particle_type=c(s["ptype"]), lo=c(self.lo), hi=c(self.hi), first=np.int64(1 if self.first else 0),
                    dt_last=np.float64(self.dt_last), hmean_prev=np.float64(self.hmean_prev), hmax_prev=np.float64(self.hmax_prev),
                    world=np.int64(self.world), forms=np.array(self.forms), d=np.float64(self.d if self.d is not None else 0.0),
-                   steps=np.int64(self.stats["steps"]))
+                   steps=np.int64(self.stats["steps"]),
+                   # what the step does beyond the core sums, and the per-particle fields that go with it (they migrate
+                   # with the particles: the snapshot holds them in the owned order like everything else)
+                   with_drag=np.int64(self.with_drag), with_species=np.int64(self.with_species),
+                   has_agb=np.int64(self.agb is not None))
+        if self.with_drag:
+            out.update(mean_grain_mass=c(s["mgm"]), mean_cross_section=c(s["mcs"]))
+        if self.with_species:
+            out["f_un"] = c(s["fun"])
         np.savez("%s.rank%d.npz" % (prefix, self.rank), **out)
         if self.world > 1:
             dist.barrier()
 
     @classmethod
     def from_snapshot(cls, prefix, backend, rank=0, world=1, **kw):
-        """Resume a decomposed run written by snapshot() with the same number of ranks."""
+        """Resume a decomposed run written by snapshot() with the same number of ranks.  The step's extras come back as
+        the run had them (with_drag / with_species default to the file's flags; the composition rows and the drag
+        coefficients are in the file); an AGB table is not stored - a run that had one must be handed it again (agb=...)."""
         z = dict(np.load("%s.rank%d.npz" % (prefix, rank), allow_pickle=False))
         if int(z["world"]) != world:
             raise ValueError("snapshot was written by %d ranks, resuming with %d" % (int(z["world"]), world))
         state = {k_: z[k_] for k_ in ("points", "velocities", "total_accel", "E_internal", "T", "mass", "mu_array",
                                        "gamma_array", "particle_type", "gid")}
+        for k_ in ("f_un", "mean_grain_mass", "mean_cross_section"):
+            if k_ in z:
+                state[k_] = z[k_]
+        kw.setdefault("with_drag", bool(int(z.get("with_drag", 0))))
+        kw.setdefault("with_species", bool(int(z.get("with_species", 0))))
+        if int(z.get("has_agb", 0)) and kw.get("agb") is None:
+            raise ValueError("the snapshot's run carried an AGB table (metallicity + yields in the species pass): pass agb=(splines, "
+                             "mapto, divisor) to from_snapshot")
         forms = str(z["forms"])
         sim = cls(state, z["lo"], z["hi"], backend, rank, world, forms=forms, d=(float(z["d"]) if forms == "loop" else None), **kw)
         sim.s["h"] = torch.as_tensor(np.ascontiguousarray(z["sizes"], dtype=np.float64)).to(sim.device)
@@ -1209,6 +1263,29 @@ class DistributedSim:
         sim.hmean_prev, sim.hmax_prev = float(z["hmean_prev"]), float(z["hmax_prev"])
         sim.stats["steps"] = int(z["steps"])
         return sim
+
+    FAILURE_COUNTERS = ("bad_accel", "bad_energy", "bad_state", "bad_h", "short_rows")
+
+    def failures(self, log_new=True):
+        """Global failure counters (include/sphx.h sphx_stats.bad_*: owned particles whose acceleration / energy / updated
+        state / kNN radius was NaN, inf or 0 before the reference's nan_to_num guards; searches that gave up short), summed
+        over the ranks since the backend's stats were reset: one all_reduce.  Reading them waits for the stream, so the
+        step does not do it by itself - call this where a driver prints its diagnostics (drv:465-468).  New ones are
+        logged (Python logging, 'sph_code_amd')."""
+        ctx = getattr(self.backend, "ctx", None)
+        st = ctx.stats() if ctx is not None else {}
+        loc = torch.tensor([float(st.get(k_, 0)) for k_ in self.FAILURE_COUNTERS], dtype=torch.float64, device=self.comm_device)
+        if self.world > 1:
+            dist.all_reduce(loc, op=dist.ReduceOp.SUM)
+        out = {k_: int(v) for k_, v in zip(self.FAILURE_COUNTERS, loc.tolist())}
+        seen = getattr(self, "_failures_seen", None) or {}
+        new = {k_: v - seen.get(k_, 0) for k_, v in out.items() if v > seen.get(k_, 0)}
+        self._failures_seen = out
+        if new and log_new and self.rank == 0:
+            import logging
+            logging.getLogger("sph_code_amd").warning("decomposed step: non-finite values met (particles, all ranks): %s  "
+                                                      "[cumulative: %s]", new, out)
+        return out
 
     def diagnostics(self):
         """Global mass-weighted net acceleration (what sph/code_running.py:465-468 prints every step), momentum, kinetic
@@ -1267,12 +1344,23 @@ def bench_main(args, rank, local_rank, world):
     if world == 1:                               # (SPHX_FORCE_DIST=1 without a launcher: a rendezvous with itself)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
+    # an explicit timeout on every collective / p2p wait: a rank that hangs (a peer died, a link did not come up) fails
+    # with the phase it was in instead of holding the node until the launcher's own limit
+    import datetime
+    tmo = datetime.timedelta(seconds=int(os.environ.get("SPHX_DIST_TIMEOUT_S", "300")))
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         comm_dev = dev
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
         comm_dev = torch.device("cpu")
+
+    def give_up(where, exc):
+        # never a re-exec, never a retry: say which rank failed where, and leave with a non-zero code (the launcher
+        # then ends the other ranks)
+        print("[sphx bench] rank %d/%d failed in %s (DistributedSim phase: %s): %s: %s"
+              % (rank, world, where, DistributedSim.phase, type(exc).__name__, exc), file=sys.stderr, flush=True)
+        os._exit(3)
     n_global = args.n * world                       # weak scaling: fixed particles per GPU
     forms = getattr(args, "forms", None) or "hydro_update"
     if forms == "loop" and args.workload in ("uniform_cube", "two_phase"):
@@ -1287,16 +1375,38 @@ def bench_main(args, rank, local_rank, world):
             dilution = "constant density: x%.3g in length" % scale
     species, drag = bool(getattr(args, "species", False)), bool(getattr(args, "drag", False))
     full = species or drag                           # these need the (N,15) composition
-    state = (ics.WORKLOADS[args.workload](n_global, size_scale=scale) if full
-             else ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale))
-    if full and state.get("f_un") is None:
-        raise SystemExit("--species / --drag need a workload that carries f_un (two_phase, dusty_sphere)")
+    # Box-filling workloads at their natural size (the default of N > 1: uniform_cube / two_phase): every rank draws ITS
+    # OWN brick's particles (ics.cube_slab, seeded per brick) - no rank builds or bisects the global state (8 x 8e6
+    # particles on an 8-GPU node otherwise).  The others: the global seeded IC, cut by recursive bisection, as before.
+    slab = args.workload in ("uniform_cube", "two_phase") and scale == 1.0 and os.environ.get("SPHX_BENCH_GLOBAL_IC") != "1"
+    state = None
+    if not slab:
+        state = (ics.WORKLOADS[args.workload](n_global, size_scale=scale) if full
+                 else ics.WORKLOADS[args.workload](n_global, light=True, size_scale=scale))
+        if full and state.get("f_un") is None:
+            raise SystemExit("--species / --drag need a workload that carries f_un (two_phase, dusty_sphere)")
     agb_table = None
     if species:
         from . import agb as agb_mod
         z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "agb_reference.npz"))
         agb_table = agb_mod.splines_from_arrays(z["tx"], z["ty"], z["coeffs"], z["mapto"], float(z["divisor"]))
-    d_loop = ics.loop_d(state, args.k) if forms == "loop" else None
+    mine = lo = hi = None
+    if slab:
+        side = 1.25e6 * ics.AU
+        lo, hi, flo, fhi = brick_regions(world, [-0.5 * side] * 3, [0.5 * side] * 3)
+        mine = ics.cube_slab(args.workload, args.n, rank, flo[rank], fhi[rank], light=not full)
+        mine["gid"] = rank * args.n + np.arange(args.n, dtype=np.int64)
+        mine = {k_: v for k_, v in mine.items() if v is not None}
+    d_loop = None
+    if forms == "loop":
+        # one d for all ranks (drv:67-68 is a global): rank 0's estimate - on its own brick when the IC is drawn per rank
+        # (the same density everywhere) - handed to the others
+        dl = torch.zeros(1, dtype=torch.float64, device=comm_dev)
+        if rank == 0:
+            dl[0] = ics.loop_d(mine if slab else state, args.k)
+        if world > 1:
+            dist.broadcast(dl, src=0)
+        d_loop = float(dl[0])
     # the same workload at the per-GPU size on ONE GPU through the fused single-GPU loop (rank 0, before the decomposed
     # run): the denominator a scaling efficiency for THIS workload needs, measured in the same process
     single = None
@@ -1311,17 +1421,21 @@ def bench_main(args, rank, local_rank, world):
         t1 = time.perf_counter()
         sim1.step(10)
         torch.cuda.synchronize()
-        single = {"ms_per_step": (time.perf_counter() - t1) / 10 * 1e3, "particles": args.n,
-                  "particle_steps_per_s": args.n * 10 / (time.perf_counter() - t1)}
+        el1 = time.perf_counter() - t1
+        single = {"ms_per_step": el1 / 10 * 1e3, "particles": args.n, "particle_steps_per_s": args.n * 10 / el1}
         sim1.ctx.close()
         del sim1, s1
-    mine, lo, hi = decompose_state(state, world, rank)
+    if not slab:
+        mine, lo, hi = decompose_state(state, world, rank)
     del state
     be = LibBackend(dev_index, k=args.k, clip_grad=getattr(args, "clip_grad", False))
-    sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev, forms=forms, d=d_loop,
-                         with_drag=drag, with_species=species, agb=agb_table)
-    for _ in range(args.warmup):
-        sim.step()
+    try:
+        sim = DistributedSim(mine, lo, hi, be, rank, world, device=dev, comm_device=comm_dev, forms=forms, d=d_loop,
+                             with_drag=drag, with_species=species, agb=agb_table)
+        for _ in range(args.warmup):
+            sim.step()
+    except Exception as exc:                  # (RuntimeError of a timed-out / failed transfer, a library error ...)
+        give_up("set-up / warm-up steps", exc)
     sim.ex.bytes_sent = 0
     sim.stats.update(ghosts=0, redo=0, migrated=0, replans=0)
     sim.host_ms.clear()
@@ -1329,10 +1443,13 @@ def bench_main(args, rank, local_rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-    torch.cuda.synchronize()
-    dist.barrier()
+    try:
+        for _ in range(args.steps):
+            sim.step()
+        torch.cuda.synchronize()
+        dist.barrier()
+    except Exception as exc:
+        give_up("the timed steps", exc)
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -1350,6 +1467,7 @@ def bench_main(args, rank, local_rank, world):
               % (sim.g_cs, torch.quantile(sim.s["h"], q).tolist(), torch.quantile(sim.w_plan, q).tolist(),
                  (torch.quantile(torch.sqrt((sim.s["vel"] ** 2).sum(dim=1)), q) * sim.dt_last).tolist(), sim.dt_last,
                  sim.n_owned, sim.stats["ghosts"] / max(args.steps, 1)), file=sys.stderr, flush=True)
+    fails = sim.failures(log_new=False)      # (a collective: every rank)
     kst = be.ctx.stats()                     # rank 0's kNN launches: HIP events on the stream they ran on
     if rank == 0:
         t = float(tmax[0])
@@ -1366,10 +1484,23 @@ def bench_main(args, rank, local_rank, world):
                        "decomposition": "recursive coordinate bisection, %d regions, %d-phase p2p halo" % (world, 3 if forms == "loop" else 4),
                        "backend": backend, "cloud_size_scale": scale, "dilution": dilution,
                        "forms": forms + (" (the reference's time loop: nsc.density, del_pressure, artificial_viscosity ...)" if forms == "loop" else ""),
-                       "species_pass": species, "drag": drag},
+                       "species_pass": species, "drag": drag,
+                       "initial_condition": ("drawn per rank: each rank fills its own brick of the cube (ics.cube_slab)" if slab
+                                             else "global seeded IC on every rank, cut by recursive coordinate bisection"),
+                       "dist_timeout_s": int(tmo.total_seconds()),
+                       "build": be.ctx.build_info(),
+                       "env": {k_: v for k_, v in sorted(os.environ.items()) if k_.startswith("SPHX_")}},
             "single_gpu_same_workload": single,
+            # value / (N x the SAME workload's single-GPU rate above): the efficiency of THIS workload's decomposition.
+            # (The N = 1 line of `bench.py` is BASELINE configs[1] - the polytrope under hydro_update's sums - a different
+            # workload: a curve through both is not a scaling curve.  `bench.py --gpus 1 --workload uniform_cube --forms
+            # loop` prints the single-GPU line of this one.)
+            "scaling_efficiency_same_workload": (value / (world * single["particle_steps_per_s"])) if single else None,
             "state_check": {"finite": float(chk[1]) == 0.0, "max_speed_m_s": float(chk[0]),
-                            "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300)},
+                            "max_drift_per_step_in_mean_h": float(chk[0]) * sim.dt_last / max(sim.hmean_prev, 1e-300),
+                            # the library's failure counters over the timed steps, all ranks (sphx_stats.bad_*, by ballot in
+                            # the update kernels: what the reference's nan_to_num guards hid)
+                            "failures": fails},
             "roofline": (lambda ms, q: {"bound": "hbm", "kernel": "search (rank 0): knn_group_kernel + knn_kernel<0,2,1> (list mode)", "achieved": 192.0 * q / (ms * 1e-3) / 1e9,
                                         "peak": 8000.0, "unit": "GB/s", "frac": 192.0 * q / (ms * 1e-3) / 1e9 / 8000.0,
                                         "traffic": None,

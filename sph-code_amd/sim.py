@@ -6,11 +6,14 @@ points/velocities (N,3), mass, particle_type (f64 0/1/2), f_un (N,S), T, mu_arra
 gamma_array, E_internal, total_accel.
 """
 import ctypes as C
+import logging
 
 import numpy as np
 
 from . import _lib
 from ._lib import dp, f64
+
+log = logging.getLogger("sph_code_amd")
 
 
 class Simulation:
@@ -80,6 +83,24 @@ class Simulation:
         c = self.ctx
         c.check(c.lib.sphx_step(c.h, int(nsteps), self.k, self.dist, 1 if self.first else 0, float(fixed_dt)))
         self.first = False
+        self._log_failures()
+
+    FAILURE_COUNTERS = ("bad_accel", "bad_energy", "bad_state", "bad_h", "short_rows")
+
+    def failures(self):
+        """-> dict of the library's failure counters (include/sphx.h sphx_stats: particles whose acceleration / energy /
+        updated state / kNN radius was NaN, inf or 0 before the reference's nan_to_num guards, drv:233-238,460-463,490;
+        searches that gave up short), summed since the last reset_stats().  All zero in a sane run."""
+        st = self.ctx.stats()
+        return {k_: int(st[k_]) for k_ in self.FAILURE_COUNTERS}
+
+    def _log_failures(self):
+        f = self.failures()
+        seen = getattr(self, "_failures_seen", None) or dict.fromkeys(self.FAILURE_COUNTERS, 0)
+        new = {k_: f[k_] - seen.get(k_, 0) for k_ in f if f[k_] > seen.get(k_, 0)}
+        self._failures_seen = f
+        if new:
+            log.warning("sphx step: non-finite values met (particles): %s  [cumulative: %s]", new, f)
 
     def download(self):
         n = self.n
@@ -93,8 +114,10 @@ class Simulation:
             dp(out["T"]), dp(out["sizes"]), dp(out["densities"]), dp(out["num_densities"]),
             dp(out["visc_heat"]), C.cast(C.byref(dt), _lib.c_double_p)))
         out["dt"] = dt.value
-        # P_i = n_i k_B T_i: the reference forms it and drops it (commented out at nsc:608); derived here
-        out["pressure"] = out["num_densities"] * self.ctx.constants().k_B * out["T"]
+        # P_i = n_i k_B T_i with n and T of the instant the last step's sums were formed at (the reference forms it and
+        # drops it, nsc:608; out["T"] is the temperature AFTER the update, drv:491 - not the one n_i belongs to)
+        out["pressure"] = np.empty(n)
+        c.check(c.lib.sphx_state_download_pressure(c.h, dp(out["pressure"])))
         return out
 
     def download_species(self):
@@ -154,3 +177,4 @@ class Simulation:
 
     def reset_stats(self):
         self.ctx.reset_stats()
+        self._failures_seen = None

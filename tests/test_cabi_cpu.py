@@ -112,3 +112,26 @@ def test_pinned_pool_falls_back_to_ordinary_memory_without_a_gpu():
     b = _lib.pinned.empty((10, 3), np.float64)              # small: never pooled
     assert b.shape == (10, 3)
     del a
+
+
+def test_product_library_carries_no_experiment_switches():
+    """Timing experiments and diagnostics that add launches or change results (SPHX_*_EXP*, SPHX_KNN_ABL, *_PROF,
+    SPHX_KG_DEBUG) are compiled in only with -DSPHX_EXPERIMENTS; the shipped libsphx.so must not even hold their names,
+    and says so in sphx_build_info."""
+    import sph_code_amd._lib as L
+    lib = L.load_library()
+    if os.environ.get("SPHX_LIB") or "SPHX_EXPERIMENTS" in os.environ.get("SPHX_EXTRA_FLAGS", ""):
+        pytest.skip("an experiment build was asked for")
+    info = lib.sphx_build_info().decode()
+    assert "experiments=0" in info and "knn_prof" not in info, info
+    blob = open(L.LIB_PATH, "rb").read()
+    for name in (b"SPHX_KG_EXP_NOAMB", b"SPHX_EXP_NO_AGB", b"SPHX_KNN_ABL", b"SPHX_BLOB_EXP", b"SPHX_PASS_EXP",
+                 b"SPHX_KG_PROF", b"SPHX_KNN_PROF", b"SPHX_KG_DEBUG"):
+        assert name not in blob, name
+    assert re.search(rb"SPHX_[A-Z_]*EXP", blob) is None
+    # the tunables that remain are read in ONE place, sphx_create
+    for f in os.listdir(os.path.join(ROOT, "sph-code_amd", "csrc")):
+        if f.endswith((".hip", ".h")) and f != "sphx_api.hip":
+            src = open(os.path.join(ROOT, "sph-code_amd", "csrc", f)).read()
+            src = re.sub(r"#ifdef SPHX_EXPERIMENTS.*?#e(ndif|lse)", "", src, flags=re.S)
+            assert "getenv" not in src, f

@@ -409,6 +409,11 @@ def test_need_map_kernel_matches_tensor_form():
         a, b = sim(Plain(), pos[sl], w[sl]), sim(be, pos[sl], w[sl])
         assert a.dtype == b.dtype == torch.uint8 and a.shape == b.shape
         assert torch.equal(a, b), int((a != b).sum())
+    # a NaN reach (a broken radius) claims everything in both forms - it must not drop out, nor mask its cell's other claims
+    wn = w[8:400].clone()
+    wn[17] = float("nan")
+    a, b = sim(Plain(), pos[8:400], wn), sim(be, pos[8:400], wn)
+    assert torch.equal(a, b) and int(b.sum()) == G ** 3
     assert 0 < int(sim(be, pos[8:400], w[8:400]).sum()) < G ** 3      # a non-trivial map
     torch.cuda.synchronize()
 

@@ -243,7 +243,7 @@ def test_step_trajectory_vs_oracle(workload):
     from oracle import sph_oracle as orc
     import sph_code_amd.ics as ics
     from sph_code_amd.sim import Simulation
-    n, K, nsteps = 4096, 40, 10
+    n, K, nsteps = (10000 if workload == "uniform_sphere" else 4096), 40, 10      # uniform_sphere at 1e4: BASELINE configs[0]
     s0 = ics.WORKLOADS[workload](n)
     fixed_dt = ics.cfl_dt(s0, K) if workload == "sedov" else 0.0     # blast: Courant-limited step
     sim = Simulation(s0, n_neigh=K)
@@ -562,8 +562,11 @@ def test_full_size_properties(nsc):
 
 
 @pytest.mark.timeout(600)
-def test_timed_step_path_equals_array_path_at_full_size(nsc):
-    """The path bench.py times - lean / grouped search kernels, blob order, LDS-form passes, XCD remap, 15 625
+@pytest.mark.parametrize("workload", ["polytrope", "sedov"])
+def test_timed_step_path_equals_array_path_at_full_size(nsc, workload):
+    """(sedov = BASELINE configs[2]: the blast under a Courant-limited fixed step - under the reference's dt >= dt_0/5 it
+    reaches inf within 3 steps; its strong density gradient sends other groups to the list-mode kernel.)
+    The path bench.py times - lean / grouped search kernels, blob order, LDS-form passes, XCD remap, 15 625
     workgroups - at the timed size (10^6-particle polytrope), two steps (un-hinted first search, hinted second):
     h, rho, n, visc_heat and the updated x, v, a, E, T equal, BIT FOR BIT, what the array API gives on the same
     state: compat.neighbors (sample-checked against SciPy at this size by test_full_size_properties) ->
@@ -574,7 +577,8 @@ def test_timed_step_path_equals_array_path_at_full_size(nsc):
     from sph_code_amd import _lib
     from sph_code_amd.sim import Simulation
     n, K = 1_000_000, 40
-    s = ics.polytrope_sphere(n)
+    s = ics.WORKLOADS[workload](n)
+    fixed_dt = ics.cfl_dt(s, K) if workload == "sedov" else 0.0
     sim = Simulation(s, n_neigh=K)
     ctx = _lib.Context(0)
     dev = torch.device("cuda:0")
@@ -584,8 +588,9 @@ def test_timed_step_path_equals_array_path_at_full_size(nsc):
     tm, tmu, tgam, tpt = t(s["mass"]), t(s["mu_array"]), t(s["gamma_array"]), t(s["particle_type"])
     cur = dict(points=s["points"], velocities=s["velocities"], total_accel=np.zeros((n, 3)),
                E_internal=s["E_internal"], T=s["T"])
+    want_bad = dict(bad_accel=0, bad_energy=0)
     for it in range(2):
-        sim.step(1)
+        sim.step(1, fixed_dt=fixed_dt)
         got = sim.download()
         p, v = nsc.clamp_state(cur["points"], cur["velocities"])
         idx, _, d, nontriv, h = nsc.neighbors(p, np.inf, K)
@@ -596,7 +601,13 @@ def test_timed_step_path_equals_array_path_at_full_size(nsc):
         assert np.array_equal(got["num_densities"], nden), "n, step %d" % it
         assert np.array_equal(got["visc_heat"], vh, equal_nan=True), "visc_heat, step %d" % it
         ct = nsc.crossing_time(idx, v, h, s["particle_type"])
-        assert got["dt"] == pytest.approx(nsc.timestep(ct, it == 0), rel=1e-12)
+        assert got["dt"] == (fixed_dt if fixed_dt > 0 else pytest.approx(nsc.timestep(ct, it == 0), rel=1e-12))
+        # what the update's nan_to_num guards (drv:460-463, 490) are about to hide, as the library counts it
+        with np.errstate(all="ignore"):
+            want_bad["bad_accel"] += int((~np.isfinite(ha).all(axis=1) | ~np.isfinite(va).all(axis=1)).sum())
+            want_bad["bad_energy"] += int((~np.isfinite(cur["E_internal"]) | ~np.isfinite(vh * got["dt"])).sum())
+        # P_i = n_i k_B T_i, both of the instant of the sums (sphx_state_download_pressure)
+        assert np.array_equal(got["pressure"], nden * nsc.k * cur["T"]), "pressure, step %d" % it
         pos, vel, acc, E = t(p), t(v), t(cur["total_accel"]), t(cur["E_internal"])
         T = torch.zeros_like(E)
         tha, tva, tvh = t(ha), t(va), t(vh)
@@ -610,7 +621,213 @@ def test_timed_step_path_equals_array_path_at_full_size(nsc):
             assert np.array_equal(got[key], cur[key], equal_nan=True), "%s, step %d" % (key, it)
     st = sim.stats()
     assert st["steps"] == 2
+    # The failure counters (sphx_stats.bad_*) agree with the array path's own NaNs - and they are not zero: under
+    # hydro_update's sums E += visc_heat dt takes E below zero on nearly half of the particles in the FIRST step (the sign of
+    # nsc:651-654), T = E mu m_h / (gamma m k) follows, sqrt(gamma k T / mu amu) of nsc:647 is NaN from the second
+    # step on, and with it every viscous sum: the reference's nan_to_num (drv:460-463, 490) then switches the viscosity off
+    # for good.  Reproduced bit for bit above (equal_nan) and by the CPU restatement; counted here.
+    f = sim.failures()
+    assert f["bad_accel"] == want_bad["bad_accel"] and f["bad_energy"] == want_bad["bad_energy"], (f, want_bad)
+    assert f["bad_h"] == 0 and f["short_rows"] == 0 and f["bad_state"] == 0, f
+    if workload == "polytrope":
+        assert f["bad_accel"] > 0.99 * n
     ctx.close()
+
+
+def _loop_array_step(nsc, cur, s, d, K, first, with_drag, fixed_dt=0.0):
+    """One pass of the reference's time loop (drv:222-238, 437, 451-491) through the drop-in module's ARRAY functions, the
+    way the driver calls them: neighbors -> crossing_time -> density / dust_density / num_dens / del_pressure /
+    artificial_viscosity [/ net_impulse] -> the leapfrog block.  -> dict like Simulation.download()."""
+    nsc.d = d
+    p, v = nsc.clamp_state(cur["points"], cur["velocities"])
+    m, pt = s["mass"], s["particle_type"]
+    idx, _, _, _, h = nsc.neighbors(p, np.inf, K)                                               # drv:437
+    ct = nsc.crossing_time(idx, v, h, pt)                                                       # drv:222
+    dt = fixed_dt if fixed_dt > 0 else nsc.timestep(ct, first)
+    rho = nsc.density(p, m, pt, idx)                                                            # drv:451
+    rho_d = nsc.dust_density(p, m, idx, pt, h)                                                  # drv:452
+    nden = nsc.num_dens(m, p, s["mu_array"], idx)                                               # drv:453
+    drag = nsc.net_impulse(p, m, h, v, pt, idx, s["f_un"]) if with_drag else None              # drv:455
+    delp = nsc.del_pressure(p, m, pt, idx, cur["E_internal"], s["gamma_array"])                 # drv:456
+    av = nsc.artificial_viscosity(idx, p, pt, h, m, rho, v, cur["T"], s["gamma_array"], s["mu_array"])   # drv:458
+    pn, vn, tot, E, T = nsc.leapfrog(p, v, cur["total_accel"], cur["E_internal"], m, s["mu_array"], s["gamma_array"], pt,
+                                     delp, rho, av, dt, dust_densities=rho_d, viscous_drag=drag)
+    return dict(points=pn, velocities=vn, total_accel=tot, E_internal=E, T=T, sizes=h, densities=rho, num_densities=nden,
+                dt=dt, visc_heat=av[1], pressure=nden * nsc.k * cur["T"], neighbor=idx, clamped=(p, v)), drag
+
+
+def _close_to_array_path(got, ref, s0, what):
+    """Positive sums 1e-12 per element; the state against the cloud's size / its largest speed and acceleration."""
+    assert np.array_equal(got["sizes"], ref["sizes"]), "h " + what          # exact kNN of the same bits: the same radius
+    for key in ("densities", "num_densities", "pressure"):
+        np.testing.assert_allclose(got[key], ref[key], rtol=1e-12, atol=0, err_msg=key + " " + what)
+    assert got["dt"] == pytest.approx(ref["dt"], rel=1e-12), what
+    R0 = np.max(np.abs(s0["points"]))
+    for key, scale, tol in (("points", R0, 1e-13), ("velocities", np.max(np.abs(ref["velocities"])), 1e-10),
+                            ("total_accel", np.max(np.abs(ref["total_accel"])), 1e-10),
+                            ("E_internal", np.max(np.abs(ref["E_internal"])), 1e-12), ("T", np.max(np.abs(ref["T"])), 1e-12),
+                            ("visc_heat", np.max(np.abs(ref["visc_heat"])), 1e-10)):
+        fin = np.isfinite(ref[key])
+        assert (np.isfinite(got[key]) == fin).all(), key + " " + what
+        assert np.max(np.abs(got[key] - ref[key])[fin]) <= tol * scale, (key, what, np.max(np.abs(got[key] - ref[key])[fin]) / scale)
+
+
+@pytest.mark.timeout(600)
+def test_timed_loop_form_path_equals_array_path_at_full_size(nsc):
+    """BASELINE configs[3]'s workload on one GPU, the default of `bench.py --gpus N`: the reference's own IC (uniform cube,
+    drv:62,132) stepped by the LOOP FORMS (drv:451-458), 10^6 particles, two steps (un-hinted first search; hinted second:
+    grouped kernel, ~7 % of the queries - the cube's faces - through the list-mode kernel, blob order, the loop forms' LDS
+    passes of sphx_loopforms.hip).  Each step is compared, on the state the loop itself held before it, with the drop-in
+    module's array functions composed as the driver composes them (_loop_array_step: golden-pinned gather kernels + the
+    fixture-pinned leapfrog block): h bit for bit; sums, dt, P, x, v, a, E, T to the tolerances of SURVEY 8c."""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K = 1_000_000, 40
+    s = ics.uniform_cube(n)
+    d = ics.loop_d(s, K)
+    sim = Simulation(s, n_neigh=K, forms="loop", d=d)
+    cur = dict(points=s["points"], velocities=s["velocities"], total_accel=np.zeros((n, 3)), E_internal=s["E_internal"], T=s["T"])
+    for it in range(2):
+        sim.step(1)
+        got = sim.download()
+        ref, _ = _loop_array_step(nsc, cur, s, d, K, it == 0, False)
+        _close_to_array_path(got, ref, s, "step %d" % it)
+        cur = got                                      # the next step starts from the loop's own bits
+    st = sim.stats()
+    assert st["fallback_queries"] > 0.01 * n          # the second search did hand the faces' queries on
+    assert sim.failures() == dict.fromkeys(sim.FAILURE_COUNTERS, 0)
+
+
+@pytest.mark.timeout(600)
+def test_timed_two_phase_species_drag_path_equals_array_path_at_full_size(nsc):
+    """BASELINE configs[4]'s workload at one GPU's share: two-phase cloud (90 % gas / 10 % dust particles), 10^6 particles,
+    loop forms + species pass (nsc:624-627) with the fused metallicity (drv:663) and AGB yields (config_helper.py:183-189)
+    + gas-dust drag with its ordered scatter (nsc:719-742), one step through the fused loop (blob_species_kernel,
+    blob_drag_kernel, DragScatter) against the array API: F vs compat.hydro_update(...)[5], Z and the yields recomputed
+    from it (sphx_agb_yields, pinned by tests/test_agb.py), the drag terms through the update they enter (total_accel of
+    the leapfrog block fed with compat.net_impulse)."""
+    import os
+    import sph_code_amd.ics as ics
+    import sph_code_amd.agb as agb
+    from sph_code_amd.sim import Simulation
+    n, K = 1_000_000, 40
+    s = ics.two_phase(n)
+    d = ics.loop_d(s, K)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "agb_reference.npz"))
+    table = agb.splines_from_arrays(z["tx"], z["ty"], z["coeffs"], z["mapto"], float(z["divisor"]))
+    sim = Simulation(s, n_neigh=K, forms="loop", d=d, with_species=True, agb=table, with_drag=True)
+    sim.step(1)
+    got = sim.download()
+    sp = sim.download_species()
+    cur = dict(points=s["points"], velocities=s["velocities"], total_accel=np.zeros((n, 3)), E_internal=s["E_internal"], T=s["T"])
+    ref, drag = _loop_array_step(nsc, cur, s, d, K, True, True)
+    assert np.abs(drag[0]).max() > 0 and np.abs(drag[1]).max() > 0                 # drag did act (on gas and back on dust)
+    _close_to_array_path(got, ref, s, "two-phase")
+    p, v = ref["clamped"]
+    F = nsc.hydro_update(ref["neighbor"], p, s["mass"], ref["sizes"], s["f_un"], s["particle_type"], s["T"], s["mu_array"],
+                         s["gamma_array"], v)[5]
+    np.testing.assert_allclose(sp["f_un_neighbor"], F, rtol=1e-13, atol=0)
+    mu = nsc.mu_specie
+    with np.errstate(all="ignore"):
+        Z = (F[6:] * mu[6:, None]).sum(axis=0) / (F * mu[:, None]).sum(axis=0)
+    fin = np.isfinite(Z)
+    assert fin.mean() > 0.99 and (np.isnan(sp["metallicity"]) == ~fin).all()
+    np.testing.assert_allclose(sp["metallicity"][fin], Z[fin], rtol=1e-12, atol=1e-300)
+    dust, _ = agb.calculate_interpolation(s["mass"][fin], sp["metallicity"][fin], table[0], table[1], table[2], mu)
+    np.testing.assert_allclose(sp["agb_dust"][fin], dust, rtol=1e-12, atol=0)
+    assert sim.failures()["bad_h"] == 0 and sim.failures()["short_rows"] == 0
+
+
+def test_end_to_end_deviation_budget_vs_the_references_own_search(nsc, golden):
+    """What SURVEY Q5 / F8 leaves unpinned, in numbers.  The reference searches with cKDTree.query(eps=0.1) (nsc:544): an
+    APPROXIMATE k-th neighbour, so its h_i lies in [h_exact, 1.1 h_exact] and its list may hold a farther particle in place
+    of a nearer one.  The drop-in returns the exact kNN.  Every sum is pinned GIVEN the reference's list (the tests above);
+    this one runs the two calls end to end - compat.neighbors -> compat.hydro_update - on the reference's own inputs and
+    states how far the results sit from the reference's own outputs (fixtures nb_h, hu_density_calc, hu_hydro_accel),
+    as a budget that must hold on all five cases.  Measured (CPU oracle = this path to 1e-13): rows with the identical
+    radius 92.7 .. 98.6 %; h_ref / h - 1: max 1.6 .. 3.6 %, mean 1e-4 .. 6e-4; rho: median 0 .. 3.4e-4, 99th percentile
+    0.7 .. 1.3 %, max 1.4 .. 4.2 % (W takes the NEIGHBOUR's radius, nsc:587-588, so a particle's own h error does not enter
+    its own rho at all; what enters is the few per cent of its neighbours that have one); hydro_accel, a cancelling sum
+    with an unclipped r^4 tail (F7): median deviation 0 .. 2e-3 of the median |a|, and O(1) on the per cent of rows whose
+    list differs."""
+    g = golden
+    K = int(g["K"])
+    idx, _, d, _, h = nsc.neighbors(g["points"], float(g["dist_bound"]), K)
+    out = nsc.hydro_update(*hydro_args(g, neighbor=idx, sizes=h))
+    rel_h = g["nb_h"] / h - 1.0
+    assert (rel_h >= -1e-15).all() and (rel_h <= 0.1 + 1e-15).all()          # the (1 + eps) guarantee, per particle
+    same = rel_h == 0.0
+    assert same.mean() >= 0.92, same.mean()
+    assert rel_h.max() <= 0.05 and rel_h.mean() <= 1e-3, (rel_h.max(), rel_h.mean())
+    rows_equal = (np.sort(idx, axis=1) == np.sort(g["nb_idx"].astype(np.int64), axis=1)).all(axis=1)
+    assert (rows_equal == same).mean() > 0.999           # a different radius IS a different list (and vice versa)
+    with np.errstate(all="ignore"):
+        rr = np.abs(out[3] / g["hu_density_calc"] - 1.0)
+    rr = rr[np.isfinite(rr)]
+    assert rr.max() <= 0.06 and np.median(rr) <= 5e-4 and np.percentile(rr, 99) <= 0.02, (rr.max(), np.median(rr))
+    ha, ha_ref = out[0], g["hu_hydro_accel"]
+    fin = np.isfinite(ha_ref).all(axis=1) & np.isfinite(ha).all(axis=1)
+    dev = np.linalg.norm(ha - ha_ref, axis=1)[fin] / np.median(np.linalg.norm(ha_ref, axis=1)[fin])
+    assert np.median(dev) <= 3e-3, np.median(dev)
+    # rows whose list is the reference's: every sum of theirs that reads only their own list's h_j - all of them equal -
+    # is the reference's to rounding
+    allsame = same & np.all(same[np.minimum(idx, len(same) - 1)], axis=1)
+    if allsame.sum() > 10:
+        np.testing.assert_allclose(out[3][allsame], g["hu_density_calc"][allsame], rtol=1e-13)
+
+
+def test_failure_counters_say_what_nan_to_num_hid():
+    """per-pass failure counters surfaced to Python.  The reference's loop guards itself with
+    nan_to_num alone (drv:233-238, 460-463, 490-491) and carries on; so does the step - sphx_stats.bad_* count how often
+    the guard was needed, by ballot inside the update and h-sum kernels (Simulation.failures(); Simulation.step logs what
+    is new).  (1) The reference's time loop - the loop forms - on a sane cloud: all zero.  (2) hydro_update's sums: zero
+    after the first step, every particle from the second on - E += visc_heat dt drives E, and with it T (drv:491), below
+    zero on nearly half of the particles in step one (the sign of nsc:651-654); sqrt(gamma k T / mu amu)
+    (nsc:647) is then NaN, every viscous sum with it, and nan_to_num switches the viscosity off for good - the CPU
+    restatement does the same.  (3) Coincident particles: kNN radius 0 (bad_h), 1/h^9 sums NaN (bad_accel); a NaN energy:
+    bad_energy.  (4) reset_stats clears them."""
+    import logging
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n = 3000
+    base = ics.uniform_sphere(n)
+    zero = dict.fromkeys(Simulation.FAILURE_COUNTERS, 0)
+    sim = Simulation(base, n_neigh=40, forms="loop", d=ics.loop_d(base, 40))
+    sim.step(3)
+    assert sim.failures() == zero
+    sim = Simulation(base, n_neigh=40)
+    sim.step(1)
+    assert sim.failures() == zero
+    assert (sim.download()["T"] < 0).mean() > 0.3                 # the first step's heating has the wrong sign for these
+    sim.step(1)
+    f = sim.failures()
+    assert f["bad_accel"] == n and f["bad_energy"] == n and f["bad_h"] == 0 and f["bad_state"] == 0, f
+    ref = orc.step(orc.step(base, n_neigh=40, eps=0.0, first=True), n_neigh=40, eps=0.0, first=False)      # the oracle agrees
+    with np.errstate(all="ignore"):
+        p, v = orc.clamp_state(ref["points"], ref["velocities"])
+        out = orc.hydro_update(ref["neighbor"], p, ref["mass"], ref["sizes"], np.ones((n, 1)), ref["particle_type"], ref["T"],
+                               ref["mu_array"], ref["gamma_array"], v)
+    assert not np.isfinite(out[2]).any()
+    s = {k_: (v.copy() if hasattr(v, "copy") else v) for k_, v in base.items()}
+    s["points"][:100] = s["points"][0]                        # 100 coincident particles: K = 40 of them at distance 0
+    s["E_internal"] = s["E_internal"].copy(); s["E_internal"][200] = np.nan
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    logging.getLogger("sph_code_amd").addHandler(handler)
+    try:
+        sim = Simulation(s, n_neigh=40)
+        sim.step(1)
+    finally:
+        logging.getLogger("sph_code_amd").removeHandler(handler)
+    f = sim.failures()
+    assert f["bad_h"] == 100, f                               # exactly the coincident ones
+    assert 100 <= f["bad_accel"] < n, f                       # their own sums (1/h^9) and their neighbours'
+    assert 1 <= f["bad_energy"] < n, f
+    assert records and "bad_h" in records[0].getMessage()     # Simulation.step logged it
+    sim.reset_stats()
+    assert sim.failures() == zero
 
 
 @pytest.mark.timeout(180)

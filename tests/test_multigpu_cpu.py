@@ -316,7 +316,7 @@ def test_world2_gloo_loop_forms_on_the_reference_ic(tmp_path):
     assert got["stats"][0] > 0
 
 
-def _snap_worker(rank, world, port, n, out_dir):
+def _snap_worker(rank, world, port, n, out_dir, dusty=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -324,34 +324,50 @@ def _snap_worker(rank, world, port, n, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sph_code_amd.ics as ics
     from sph_code_amd import multigpu as mg
-    state = ics.polytrope_sphere(n, light=True)
+    state = ics.dusty_sphere(n) if dusty else ics.polytrope_sphere(n, light=True)
     mine, lo, hi = mg.decompose_state(state, world, rank)
-    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu")
+    kw = dict(with_drag=True, with_species=True) if dusty else {}
+    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **kw)
     sim.step(); sim.step()
     prefix = os.path.join(out_dir, "snap")
     sim.snapshot(prefix)
     diag = sim.diagnostics()
     sim.step(); sim.step()
     a = sim.owned_numpy()
-    sim2 = mg.DistributedSim.from_snapshot(prefix, OracleBackend(K), rank, world, device="cpu")
+    sim2 = mg.DistributedSim.from_snapshot(prefix, OracleBackend(K), rank, world, device="cpu")     # (no kwargs: the file's flags)
     assert not sim2.first and sim2.stats["steps"] == 2
+    assert sim2.with_drag == dusty and sim2.with_species == dusty
+    assert sorted(sim2.extra_fields) == (["fun", "mcs", "mgm"] if dusty else [])
     sim2.step(); sim2.step()
     b = sim2.owned_numpy()
+    for r_ in (a, b):
+        if "f_un_neighbor" in r_:
+            r_["f_un_neighbor"] = np.ascontiguousarray(r_["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
+        for k_ in [k_ for k_, v in r_.items() if v is None]:
+            del r_[k_]
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), diag_net=diag["net_accel"], diag_n=diag["particles"],
              diag_kin=diag["kinetic"], **{"a_" + k_: v for k_, v in a.items()}, **{"b_" + k_: v for k_, v in b.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world2_snapshot_restart_and_diagnostics(tmp_path):
+@pytest.mark.parametrize("dusty", [False, True])
+def test_world2_snapshot_restart_and_diagnostics(tmp_path, dusty):
     """A decomposed run resumed from its per-rank snapshots continues like the uninterrupted one (the plan is rebuilt:
-    same neighbour sets, same sums); the diagnostics are global sums (every rank reports the same numbers)."""
+    same neighbour sets, same sums); the diagnostics are global sums (every rank reports the same numbers).
+    dusty: a two-phase run (BASELINE configs[4]'s ingredients: drag with its reverse halo + the species pass) - the
+    snapshot carries the composition rows, the drag coefficients and the two flags, and the resumed run, given NO
+    keyword, keeps doing both (it used to come back with drag and species silently off)."""
     n, world = 2400, 2
     port = _free_port()
-    mp.spawn(_snap_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_snap_worker, args=(world, port, n, str(tmp_path), dusty), nprocs=world, join=True)
     parts = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
     assert int(parts[0]["diag_n"]) == int(parts[1]["diag_n"]) == n
     assert np.array_equal(parts[0]["diag_net"], parts[1]["diag_net"]) and float(parts[0]["diag_kin"]) > 0
+    if dusty:           # the species pass ran in the resumed run too, with the same result
+        fa = np.concatenate([p["a_f_un_neighbor"] for p in parts])[np.argsort(np.concatenate([p["a_gid"] for p in parts]))]
+        fb = np.concatenate([p["b_f_un_neighbor"] for p in parts])[np.argsort(np.concatenate([p["b_gid"] for p in parts]))]
+        np.testing.assert_allclose(fb, fa, rtol=1e-12, atol=0)
     for key in ("points", "velocities", "sizes", "densities", "E_internal"):
         a = np.concatenate([p["a_" + key] for p in parts])[np.argsort(np.concatenate([p["a_gid"] for p in parts]))]
         b = np.concatenate([p["b_" + key] for p in parts])[np.argsort(np.concatenate([p["b_gid"] for p in parts]))]
