@@ -152,7 +152,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
 #endif
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc(&ctx->pinned, 16384, hipHostMallocDefault) == hipSuccess;
     ctx->own_stream = ctx->stream;
     for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
     for (int r = 0; ok && r < 3; ++r)
@@ -166,7 +166,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
                  hipEventCreateWithFlags(&ctx->ev_perm_fork, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_perm, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = sphx_ensure(ctx, ctx->scal, SC_NSLOTS * 8) == SPHX_OK &&
-                 hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess;
+                 hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream) == hipSuccess &&
+                 sphx_ensure(ctx, ctx->badc, (size_t)BADC_BUCKETS * BADC_STRIDE * sizeof(u64)) == SPHX_OK &&
+                 hipMemsetAsync(ctx->badc.p, 0, (size_t)BADC_BUCKETS * BADC_STRIDE * sizeof(u64), ctx->stream) == hipSuccess;
     if (!ok) {
         fprintf(stderr, "sphx_create: HIP initialisation failed on device %d\n", device);
         delete ctx;
@@ -199,7 +201,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->Tprev};
+                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->Tprev, &ctx->badc};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -430,6 +432,7 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
         ctx->sp = sp;
     }
     HIPCHK(hipMemsetAsync(ctx->scal.p, 0, SC_NSLOTS * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->badc.p, 0, (size_t)BADC_BUCKETS * BADC_STRIDE * sizeof(u64), ctx->stream));
     ctx->ct_primed = false;       // SC_CT_BITS was just zeroed: the next pass 2 must prime it again
     ctx->nbr_api_valid = false;
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -798,8 +801,7 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     ctx->stats.retries = (int64_t)sc[SC_RETRY];
     ctx->stats.fallback_queries = (int64_t)(u32)sc[SC_NFAILQ];
     ctx->stats.short_rows = (int64_t)sc[SC_SHORT];
-    ctx->stats.bad_accel = (int64_t)sc[SC_BAD_ACCEL]; ctx->stats.bad_energy = (int64_t)sc[SC_BAD_ENERGY];
-    ctx->stats.bad_state = (int64_t)sc[SC_BAD_STATE]; ctx->stats.bad_h = (int64_t)sc[SC_BAD_H];
+    SPHX_TRY(sphx_badc_read(ctx));
 #ifdef SPHX_EXPERIMENTS
     if (ctx->knn_prof_print) {
         const char* nm[4] = {"in-box", "-", "outside the box", "-"};
@@ -969,16 +971,24 @@ extern "C" int sphx_state_download_species(sphx_ctx* ctx, double* F, double* Z, 
     return SPHX_OK;
 }
 
+int sphx_badc_read(sphx_ctx* ctx) {
+    u64* hb = (u64*)((char*)ctx->pinned + 8192);
+    HIPCHK(hipMemcpyAsync(hb, ctx->badc.p, (size_t)BADC_BUCKETS * BADC_STRIDE * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    u64 tot[4] = {0, 0, 0, 0};
+    for (int b = 0; b < BADC_BUCKETS; ++b)
+        for (int q = 0; q < 4; ++q) tot[q] += hb[b * BADC_STRIDE + q];
+    ctx->stats.bad_accel = (int64_t)tot[BAD_ACCEL]; ctx->stats.bad_energy = (int64_t)tot[BAD_ENERGY];
+    ctx->stats.bad_state = (int64_t)tot[BAD_STATE]; ctx->stats.bad_h = (int64_t)tot[BAD_H];
+    return SPHX_OK;
+}
+
 extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
     if (!ctx || !out) return SPHX_E_ARG;
     SPHX_TRY(sphx_dev_collect(ctx));
     if (ctx->map_perm) {               // the device-pointer API has no sphx_step to read the failure counters back: here
         HIPCHK(hipSetDevice(ctx->device));
-        u64* hb = (u64*)((char*)ctx->pinned + 3584);
-        HIPCHK(hipMemcpyAsync(hb, ctx->scal.as<u64>() + SC_BAD_ACCEL, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        ctx->stats.bad_accel = (int64_t)hb[0]; ctx->stats.bad_energy = (int64_t)hb[1];
-        ctx->stats.bad_state = (int64_t)hb[2]; ctx->stats.bad_h = (int64_t)hb[3];
+        SPHX_TRY(sphx_badc_read(ctx));
     }
     *out = ctx->stats;
     return SPHX_OK;
@@ -995,7 +1005,7 @@ extern "C" int sphx_reset_stats(sphx_ctx* ctx) {
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_CAND, 0, 2 * sizeof(u64), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_SHORT, 0, sizeof(u64), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->scal.as<u64>() + SC_BAD_ACCEL, 0, 4 * sizeof(u64), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->badc.p, 0, (size_t)BADC_BUCKETS * BADC_STRIDE * sizeof(u64), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPHX_OK;
 }

@@ -4,11 +4,18 @@
 #pragma once
 #include "sphx_internal.h"
 
+#ifndef BLOB_P
 #define BLOB_P 128                  // particles per workgroup
-#define BLOB_T 256                  // threads of the dedup kernel (two per particle)
+#endif
+#define BLOB_T (2 * BLOB_P)          // threads of the dedup kernel (two per particle)
 #define LPP SPHX_SUM_PARTS           // lanes per particle in the passes = partial sums per total
 #define PASS_T (BLOB_P * LPP)       // threads per workgroup of the passes
+#ifndef BLOB_S
 #define BLOB_S 960                  // hash-table entries = image slots
+#endif
+#ifndef PASS_MINW
+#define PASS_MINW 4                  // waves per SIMD the pass kernels are compiled for
+#endif
 #define BLOB_PROBES 96
 #define SLOT_NONE 0xFFFFu           // no neighbour (list shorter than K)
 #define SLOT_OVER 0xFFFEu           // neighbour not staged: read it from global memory
@@ -87,7 +94,10 @@ __device__ __forceinline__ double group_max(double v) {
 // Fill the workgroup's LDS: slot lists (16-B pieces; rows k..KPAD(k) read as "no neighbour") and the
 // records of the occupied table entries.  NSIDE 1: one 8-B side value per slot.  NSIDE 2 (pass 3):
 // g0 replaces the record's last double (cs, unused there) and g1 is the side value.  All global
-// loads are issued before the first use.
+// loads are issued before the first use.  (One lane per record: four lanes per record - 16 whole records per load
+// instruction instead of 64 quarter records, a quarter of the distinct lines per instruction - measured SLOWER, passes
+// +10 % (162 / 181 / 149 -> 180 / 200 / 163 us): eight rounds of loads per thread instead of two, 4-way conflicts on the
+// image stores; round 3.)
 template <int NSIDE, class Rec>
 __device__ __forceinline__ void stage(double2* img, double* side, u16* tile, const Rec* __restrict__ rec,
                                       const double* __restrict__ g0, int g0_stride,

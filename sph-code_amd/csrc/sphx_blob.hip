@@ -276,7 +276,7 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
 // EXP != 0: timing experiments on an extra, discarded launch (SPHX_BLOB_EXP): 1 = staging only,
 // 2 = neighbour loop only (image not filled), 3 = both but no global stores at the end.
 template <int EXP>
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_density_kernel(int n, int npad, int k, int nblk, int clip,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_density_kernel(int n, int npad, int k, int nblk, int clip,
                                                               const int* __restrict__ nbr,
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
@@ -384,7 +384,7 @@ __device__ __forceinline__ void pi_batch(double& s_pi, double& maxrel, const uns
     }
 }
 
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_pi_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_pi_kernel(int n, int npad, int k, int nblk,
                                                          const int* __restrict__ nbr,
                                                          const u16* __restrict__ slot16,
                                                          const int* __restrict__ uniq,
@@ -512,7 +512,7 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
     }
 }
 
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, int npad, int k, int nblk, int clip,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_visc_kernel(int n, int npad, int k, int nblk, int clip,
                                                            const int* __restrict__ nbr,
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_visc_kernel(int n, 
 // Sums: the lane's positions k = q mod 4 in ascending k, then (p0 + p1) + (p2 + p3) as in the other LDS passes.
 // SPEC_MAXM: list positions per lane the registers are sized for (K <= 40: 10; else 16)
 template <int SPEC_MAXM>
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_species_kernel(int n, int npad, int k, int nblk, int S,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_species_kernel(int n, int npad, int k, int nblk, int S,
                                                               const int* __restrict__ nbr,
                                                               const u16* __restrict__ slot16,
                                                               const int* __restrict__ uniq,
@@ -760,7 +760,7 @@ int sphx_blob_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun,
 // reduction sorts by key).  FILL = false: the counting pass of the scatter plan (sphx_drag_scatter_plan).
 #define DRAG_XLDS (BLOB_S * (2 * sizeof(int) + 1))          // count, base, dust flag per image slot
 template <bool FILL>
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_drag_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_drag_kernel(int n, int npad, int k, int nblk,
                                                            const int* __restrict__ nbr,
                                                            const u16* __restrict__ slot16,
                                                            const int* __restrict__ uniq,

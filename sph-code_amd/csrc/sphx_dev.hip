@@ -268,7 +268,7 @@ struct DevIntegArgs {
     double* dt_out;
     int first;
     double fixed_dt, dt_0, max_age;
-    u64* counters;                // failure counters (SC_BAD_*)
+    u64* counters;                // failure counters (BAD_*)
 };
 __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
     }
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     double v[3], pa[3], vis[3];
-    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, SC_BAD_ACCEL)
+    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, BAD_ACCEL)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         v[c] = a.vel[3 * (size_t)i + c];
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(256) void dev_integrate_kernel(DevIntegArgs a) {
         bool bad_st = false;
 #pragma unroll
         for (int c = 0; c < 3; ++c) bad_st = bad_st || !sphx_finite(x[c]) || !sphx_finite(v[c]);
-        sphx_count_bad(a.counters, SC_BAD_ACCEL, bad_acc);
-        sphx_count_bad(a.counters, SC_BAD_ENERGY, bad_en);
-        sphx_count_bad(a.counters, SC_BAD_STATE, bad_st);
+        sphx_count_bad(a.counters, BAD_ACCEL, bad_acc);
+        sphx_count_bad(a.counters, BAD_ENERGY, bad_en);
+        sphx_count_bad(a.counters, BAD_STATE, bad_st);
     }
 }
 // the drag terms handed over by sphx_dev_set_drag_terms are consumed by the next update
@@ -376,7 +376,7 @@ extern "C" int sphx_dev_integrate(sphx_ctx* ctx, int64_t n_owned, double* pos, d
     take_drag_terms(ctx, a);
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = nullptr; a.dt_out = nullptr; a.first = 0; a.fixed_dt = 0.0; a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
-    a.counters = ctx->scal.as<u64>();
+    a.counters = ctx->badc.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -406,7 +406,7 @@ extern "C" int sphx_dev_integrate_auto(sphx_ctx* ctx, int64_t n_owned, double* p
     a.dt = 0.0; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
-    a.counters = ctx->scal.as<u64>();
+    a.counters = ctx->badc.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;
@@ -435,7 +435,7 @@ extern "C" int sphx_dev_integrate_loop(sphx_ctx* ctx, int64_t n_owned, double* p
     a.dt = dt; a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B; a.lim = ctx->cst.pos_clamp;
     a.red2 = red2; a.dt_out = dt_out; a.first = first; a.fixed_dt = fixed_dt;
     a.dt_0 = ctx->cst.dt_0; a.max_age = ctx->cst.max_age;
-    a.counters = ctx->scal.as<u64>();
+    a.counters = ctx->badc.as<u64>();
     hipLaunchKernelGGL(dev_integrate_kernel, dim3((unsigned)((n_owned + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     return SPHX_OK;

@@ -147,12 +147,13 @@ __global__ __launch_bounds__(256) void hsum_kernel(int n, const double* h, doubl
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double v = h[i];
         if (v > 0.0 && (clip <= 0.0 || v <= clip)) { s += v; c += 1.0; }
-        nbad += (v > 0.0 && v <= DBL_MAX) ? 0u : 1u;           // 0 (coincident points), NaN, inf: SC_BAD_H
+        nbad += (v > 0.0 && v <= DBL_MAX) ? 0u : 1u;           // 0 (coincident points), NaN, inf: BAD_H
     }
     if (__ballot(nbad != 0u)) {                               // (never in a sane run)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nbad += __shfl_xor(nbad, o, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[SC_BAD_H], (u64)nbad);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(&counters[(((blockIdx.x << 2) | (threadIdx.x >> 6)) & (BADC_BUCKETS - 1)) * BADC_STRIDE + BAD_H], (u64)nbad);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
@@ -195,7 +196,7 @@ int sphx_hsum(sphx_ctx* ctx, int64_t n, const double* h) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > HSUM_BLOCKS) blocks = HSUM_BLOCKS;
     hipLaunchKernelGGL(hsum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (int)n, h, ctx->h_clip, partial, ticket,
-                       out, cnt, ctx->scal.as<u64>());
+                       out, cnt, ctx->badc.as<u64>());
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -250,7 +251,7 @@ struct IntegArgs {
     double* dt_out;
     int first;
     double fixed_dt, dt_0, max_age;
-    u64* counters;                                     // failure counters (SC_BAD_*); nullptr: not counted
+    u64* counters;                                     // failure counters (BAD_*); nullptr: not counted
 };
 __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
     const double g = (a.ptype[i] == 0.0) ? 1.0 : 0.0;
     const double v[3] = {a.vx[i], a.vy[i], a.vz[i]};
     double pa[3], vis[3];
-    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, SC_BAD_ACCEL)
+    bool bad_acc = false;                                     // (what nan_to_num is about to hide: counted, BAD_ACCEL)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (a.G) {                                            // loop forms carry the physical sign themselves
@@ -312,9 +313,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(IntegArgs a) {
         bool bad_st = false;
 #pragma unroll
         for (int c = 0; c < 3; ++c) bad_st = bad_st || !sphx_finite(x[c]) || !sphx_finite(vv[c]);
-        sphx_count_bad(a.counters, SC_BAD_ACCEL, bad_acc);
-        sphx_count_bad(a.counters, SC_BAD_ENERGY, bad_en);
-        sphx_count_bad(a.counters, SC_BAD_STATE, bad_st);
+        sphx_count_bad(a.counters, BAD_ACCEL, bad_acc);
+        sphx_count_bad(a.counters, BAD_ENERGY, bad_en);
+        sphx_count_bad(a.counters, BAD_STATE, bad_st);
     }
 }
 
@@ -341,7 +342,7 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixe
     a.dt = ctx->scal.as<double>() + SC_DT;
     a.m_h = ctx->cst.m_h; a.kB = ctx->cst.k_B;
     a.no_old = 0;
-    a.counters = ctx->scal.as<u64>();
+    a.counters = ctx->badc.as<u64>();
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
     { DevBuf t = s.T; s.T = ctx->Tprev; ctx->Tprev = t; }       // st.T: the new temperatures; Tprev: those the sums read

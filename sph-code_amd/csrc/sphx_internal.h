@@ -288,6 +288,7 @@ struct sphx_ctx {
     // of the step's sums, in the step's sorted order like rho / nden - P_i = n_i k_B T_i of ONE instant at no cost to the
     // step (sphx_state_download_pressure)
     DevBuf Tprev;
+    DevBuf badc;                  // failure counters, BADC_BUCKETS x BADC_STRIDE u64 (zeroed at sphx_create / sphx_reset_stats)
     bool has_state = false;
     int64_t step_count = 0;
     double dt_last = 0.0;
@@ -389,15 +390,22 @@ enum {
     SC_DENSEP = 14,   // u64, only grows: particles in cells of >= DENSE_CELL members (a tile's 27 such cells overflow it)
     SC_KGDBG = 16,    // u64[8]: grouped search, queries handed on by reason (diagnostics)
     SC_KNNPROF = 24,  // u64[16]: general search, cycles / queries / longest / tries by query class (-DSPHX_KNN_PROF builds)
-    // failure counters (the reference's only guard is the nan_to_num of drv:233-238, 460-463, 490-491), all
-    // u64 and only growing, counted by ballot where the values are in registers anyway - one atomic per wave that saw any:
-    SC_BAD_ACCEL = 48,   // particles whose pressure / viscous / drag acceleration was NaN or inf before drv:460-463's nan_to_num
-                         // (rho_i = 0 or NaN: a gas particle whose list holds no gas neighbour inside its kernel)
-    SC_BAD_ENERGY = 49,  // particles whose E or heat x dt was NaN or inf before drv:490's nan_to_num
-    SC_BAD_STATE = 50,   // particles whose updated position or velocity is NaN or inf (the next step's clamp will zero / clamp them)
-    SC_BAD_H = 51,       // particles whose kNN radius came out 0 (coincident points), NaN or inf
-    SC_NSLOTS = 56
+    SC_NSLOTS = 48
 };
+
+// Failure counters (the reference's only guard is the nan_to_num of drv:233-238, 460-463, 490-491), u64 and
+// only growing, counted by ballot where the values are in registers anyway: one atomic per wave that saw any.  Under
+// hydro_update's sums EVERY particle is counted from the second step on (T < 0), so the counts are spread over
+// BADC_BUCKETS cache lines by wave - 31 000 atomics per step on ONE address cost the update kernel 0.33 ms (measured), on 64
+// lines nothing - and added up on the host (ctx->badc: [bucket][BADC_STRIDE] u64).
+enum {
+    BAD_ACCEL = 0,   // pressure / viscous / drag acceleration NaN or inf before drv:460-463's nan_to_num (rho_i = 0 or NaN, T_j < 0 ...)
+    BAD_ENERGY = 1,  // E or heat x dt NaN or inf before drv:490's nan_to_num
+    BAD_STATE = 2,   // updated position or velocity NaN or inf (the next step's clamp, drv:233-238, catches them)
+    BAD_H = 3,       // kNN radius 0 (coincident points), NaN or inf
+    BADC_BUCKETS = 64, BADC_STRIDE = 16
+};
+int sphx_badc_read(sphx_ctx* ctx);          // sums the buckets into ctx->stats.bad_* (waits for the stream)
 
 // ---- kernel launch wrappers (defined in the .hip files) ---------------------------------
 // grid

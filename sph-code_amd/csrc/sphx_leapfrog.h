@@ -58,10 +58,13 @@ __device__ __forceinline__ void sphx_leapfrog_update(double dt, double x[3], dou
 
 __device__ __forceinline__ bool sphx_finite(double v) { return v - v == 0.0; }
 // failure counters of the update kernels: one ballot per class, one atomic per wave that met any (never in a sane run)
-__device__ __forceinline__ void sphx_count_bad(unsigned long long* counters, int slot, bool bad) {
+// (counters: [64 buckets][16] u64, the bucket chosen by wave - sphx_internal.h BADC_*; 1-D launches of 256 threads)
+__device__ __forceinline__ void sphx_count_bad(unsigned long long* counters, int which, bool bad) {
     const unsigned long long m = __ballot(bad);
-    if (m && (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0ull && bad)
-        atomicAdd(&counters[slot], (unsigned long long)__popcll(m));
+    if (m && (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) == 0ull && bad) {
+        const unsigned bucket = ((blockIdx.x << 2) | (threadIdx.x >> 6)) & 63u;
+        atomicAdd(&counters[bucket * 16u + (unsigned)which], (unsigned long long)__popcll(m));
+    }
 }
 
 // drv:490-491

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void loop_pass2_kernel(int n, int npad, int k,
 }
 
 // ---- LDS form (sphx_blob.h: blob image, LPP lanes per particle, persistent workgroups) ------------------
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n, int npad, int k, int nblk, double d9,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_loop1_kernel(int n, int npad, int k, int nblk, double d9,
                                                                           const int* __restrict__ nbr,
                                                                           const u16* __restrict__ slot16,
                                                                           const int* __restrict__ uniq,
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop1_kernel(int n,
     }
 }
 
-__global__ __launch_bounds__(PASS_T, PASS_T / 128) void blob_loop2_kernel(int n, int npad, int k, int nblk,
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_loop2_kernel(int n, int npad, int k, int nblk,
                                                                           const int* __restrict__ nbr,
                                                                           const u16* __restrict__ slot16,
                                                                           const int* __restrict__ uniq,

@@ -6,6 +6,7 @@ PREFIX="$1"; shift
 OUT="$ROOT/gpurun_out/ks_$PREFIX"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SPHX_BENCH_SPECIES_LINE=0      # (bench.py's extra with-species run would mix its launches into the statistics)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ks -- \
     python3 "$ROOT/bench.py" --no-cpu --device-warmup 0 --steps 20 --warmup 3 "$@" > "$OUT/run.log" 2>&1
 grep '^{' "$OUT/run.log" | tail -1 > "$ROOT/gpurun_out/${PREFIX}_bench.json"

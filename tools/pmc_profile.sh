@@ -10,6 +10,7 @@ PREFIX="$1"; shift
 OUT="$ROOT/gpurun_out/pmc_$PREFIX"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SPHX_BENCH_SPECIES_LINE=0      # (bench.py's extra with-species run would mix its launches into the statistics)
 GROUPS_=(
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
