@@ -266,9 +266,13 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
         a.rho += fmax(ms, 0.0) * W;                           // nsc:605
         a.rd += fmax(-ms, 0.0) * W;                           // nsc:606
         a.n += Nw * W;                                        // nsc:607
-        a.gx += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;      // nsc:615
-        a.gy += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
-        a.gz += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
+        // nsc:615, the pair's common factor taken out of the three components: (A_j g_b + A_i g_a) / 2 = t (dx, dy, dz) with
+        // t = (A_j c_b + A_i c_a) / 2 - 10 fp64 operations instead of 21, each a 4-cycle issue; a regrouping of
+        // the reference's products (a few ulp per term against a bound of 1e-12 x sum|term|), the same in every variant
+        const double tg = (Aj * cb + Ai * ca) * 0.5;
+        a.gx += tg * dx;
+        a.gy += tg * dy;
+        a.gz += tg * dz;
     }
 }
 
@@ -504,9 +508,8 @@ __device__ __forceinline__ void visc_batch(ViscAcc& a, const unsigned (&sl)[NB],
         const double qj = q0.d - r2, qi = hi2 - r2;
         const double cb = (CLIP && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);
         const double ca = ci * (qi * qi);
-        const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
-        const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
-        const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
+        const double tb = (Bj * cb + Bi * ca) / 2.0;                          // nsc:651, the common factor taken out (see pass 1)
+        const double bx = tb * dx, by = tb * dy, bz = tb * dz;
         a.x += bx; a.y += by; a.z += bz;
         a.h += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
     }

@@ -370,8 +370,23 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                 if ((ex * ex + ey * ey + ez * ez) * 0.9999f > Rc * Rc) nrows = 0;
             }
             const float inv_ysp = __builtin_amdgcn_rcpf((float)ysp);
-            const bool flip_y = 2.0f * fy > (float)(cy0 + cy1 + 1), flip_z = 2.0f * fz > (float)(cz0 + cz1 + 1);
+            // rows are visited CENTRE-OUT from the row of the (clamped) query, in z (outer) and in y (inner): j = 0, 1, 2 ...
+            // -> cq, cq + 1, cq - 1, cq + 2 ..., then on along the longer side
+            const int cyq = min(max((int)fyc, cy0), cy1), czq = min(max((int)fzc, cz0), cz1);
+            const int my = min(cyq - cy0, cy1 - cyq), mz = min(czq - cz0, cz1 - czq);
+            const bool up_y = cy1 - cyq > cyq - cy0, up_z = cz1 - czq > czq - cz0;
             float Rc2 = Rc * Rc;             // shrinks with the running K-th best (rows and chords still to come are clipped to it)
+            // A query FAR outside the structure (an escaper at the drv:233 clamp, 1e5 cloud radii = 1e7 cells away) and its
+            // sphere are numbers of cells fp32 cannot resolve: the relative padding above (1e-5 of 1e7 cells = 100 cells: the
+            // whole cloud) made every chord the whole row - also after K candidates were in hand and the chords should have
+            // shrunk to the thin cap nearer than the K-th best - so ONE such query read all 1e6 particles, 64 per round trip:
+            // 10 ms, the whole launch (Sedov blast under hydro_update's sums, from the step its first particle escaped).  Its
+            // range geometry is done in fp64 instead (list / level variants only; wave-uniform; padded by 1e-9 relative).
+            const bool farq = (LIST || OUTL) && (fabsf(fx) > 3e4f || fabsf(fy) > 3e4f || fabsf(fz) > 3e4f || Rc > 3e4f);
+            const double qxd = (xi - ox) * icell, qyd = (yi - oy) * icell, qzd = (zi - oz) * icell;
+            const double qycd = finite ? qyd : fmin(fmax(qyd, 0.0), (double)ny1 + 1.0), qzcd = finite ? qzd : fmin(fmax(qzd, 0.0), (double)nz1 + 1.0);
+            double Rc2d = (Rcur * icell) * (1.0 + 1e-9) + 1e-6;
+            Rc2d *= Rc2d;
 
             for (int rb = 0; rb < (ABL == 3 ? 0 : nrows); rb += 64) {
 #ifdef SPHX_KNN_PROF
@@ -387,20 +402,46 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                     int ry = r - __mul24(rz, ysp);
                     if (ry < 0) { --rz; ry += ysp; }
                     if (ry >= ysp) { ++rz; ry -= ysp; }
-                    // rows on the query's side of the range first: with K candidates in hand the rest is clipped to the
-                    // K-th best, so a query far outside (its sphere a near-planar cut through the cloud) stops at the
-                    // depth where it found them instead of walking the whole cloud
-                    const int cy = flip_y ? cy1 - ry : cy0 + ry, cz = flip_z ? cz1 - rz : cz0 + rz;
+                    // The rows nearest to the query first: with K candidates in hand the rest is clipped to the K-th best, and
+                    // the nearer the first K, the less is left.  (Until round 3 the sweep ran from the nearer END of the
+                    // range: a query outside the box in y but level with the cloud in z - the Sedov blast's first escaper,
+                    // four box widths out - then met the cloud's far cap first and its candidates in DECREASING distance:
+                    // every one passed the running threshold, 1.03e6 candidates and 2.4e7 cycles for one query.)
+                    const int offy = (ry + 1) >> 1, offz = (rz + 1) >> 1;
+                    const int cy = ry <= 2 * my ? ((ry & 1) ? cyq + offy : cyq - offy) : (up_y ? cyq + (ry - my) : cyq - (ry - my));
+                    const int cz = rz <= 2 * mz ? ((rz & 1) ? czq + offz : czq - offz) : (up_z ? czq + (rz - mz) : czq - (rz - mz));
                     // distance (in cells) from the query to the row's (y,z) cell column.  Boundary cells
                     // are half-infinite: out-of-box coordinates are clamped into them (sphx_grid.hip).
                     const float cyf = (float)cy, czf = (float)cz;
-                    const float dy = fmaxf(fmaxf(cyf - fyc, fyc - (cyf + 1.0f)) - 1e-3f, 0.0f);
-                    const float dz = fmaxf(fmaxf(czf - fzc, fzc - (czf + 1.0f)) - 1e-3f, 0.0f);
-                    const float rem = Rc2 - (dy * dy + dz * dz);
-                    if (rem >= 0.0f) {        // the row meets the sphere: chord along x
-                        const float hc = __builtin_amdgcn_sqrtf(rem) * 1.00001f + 1e-3f;   // 1 ulp: inside the padding
-                        const int rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
-                        const int rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
+                    bool meets;
+                    int rx0, rx1;
+                    if ((LIST || OUTL) && farq) {
+                        // Only the BOUNDARY rows are half-infinite (out-of-box particles are clamped into them): they are tested
+                        // against the query clamped into the grid.  An interior row holds particles whose y and z truly lie in
+                        // it, so the true - far - query applies: with the clamped one a query off in two or three axes (a corner
+                        // of the clamp cube) kept every row's whole chord however close its K-th best already was.
+                        const double qye = (cy == 0 || cy == (int)ny1) ? qycd : qyd, qze = (cz == 0 || cz == (int)nz1) ? qzcd : qzd;
+                        const double dyd = fmax(fmax((double)cy - qye, qye - ((double)cy + 1.0)) - 1e-6, 0.0);
+                        const double dzd = fmax(fmax((double)cz - qze, qze - ((double)cz + 1.0)) - 1e-6, 0.0);
+                        const double remd = Rc2d - (dyd * dyd + dzd * dzd);
+                        meets = remd >= 0.0;
+                        const double hcd = sqrt(meets ? remd : 0.0) * (1.0 + 1e-9) + 1e-6;
+                        rx0 = (int)fmin(fmax(qxd - hcd, 0.0), (double)nx1);
+                        rx1 = (int)fmin(fmax(qxd + hcd, 0.0), (double)nx1);
+                    } else {
+                        // (boundary rows against the clamped query, interior rows against the true one - see the fp64 form above:
+                        //  against the clamped query a sphere as wide as the distance to the cloud contains the whole grid, and
+                        //  an escaper a few box widths out read all 1e6 particles however near its K-th best already was)
+                        const float fye = (cy == 0 || cy == (int)ny1) ? fyc : fy, fze = (cz == 0 || cz == (int)nz1) ? fzc : fz;
+                        const float dy = fmaxf(fmaxf(cyf - fye, fye - (cyf + 1.0f)) - 1e-3f, 0.0f);
+                        const float dz = fmaxf(fmaxf(czf - fze, fze - (czf + 1.0f)) - 1e-3f, 0.0f);
+                        const float rem = Rc2 - (dy * dy + dz * dz);
+                        meets = rem >= 0.0f;
+                        const float hc = __builtin_amdgcn_sqrtf(meets ? rem : 0.0f) * 1.00001f + 1e-3f;   // 1 ulp: inside the padding
+                        rx0 = (int)fminf(fmaxf(fx - hc, 0.0f), nx1);
+                        rx1 = (int)fminf(fmaxf(fx + hc, 0.0f), nx1);
+                    }
+                    if (meets) {        // the row meets the sphere: chord along x
                         // < 2^23 cells in all: 24-bit multiplies, 32-bit byte offsets
                         const int row = __mul24(__mul24(cz, gny) + cy, gnx);
                         const char* cs = (const char*)cstart;
@@ -530,8 +571,13 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                                 // nothing beyond the K-th best can still enter: clip what remains of this structure to it
                                 // (same padding as the trial radius; an oversized sphere - a stale hint, a ladder step too
                                 // far - then costs about what the right one would have)
-                                const float rk = (float)(sqrt(__longlong_as_double((long long)kth)) * icell) * 1.00001f + 2e-3f;
+                                const double rkd = sqrt(__longlong_as_double((long long)kth)) * icell;
+                                const float rk = (float)rkd * 1.00001f + 2e-3f;
                                 Rc2 = fminf(Rc2, rk * rk);
+                                if ((LIST || OUTL) && farq) {
+                                    const double rp = rkd * (1.0 + 1e-9) + 1e-6;
+                                    Rc2d = fmin(Rc2d, rp * rp);
+                                }
                             }
 #ifdef SPHX_KNN_PROF
                             d_iter += (u64)(clock64() - td0);

@@ -184,9 +184,10 @@ __global__ __launch_bounds__(256) void pass_density_kernel(int n, int npad, int 
         a_rho[u & (SPHX_SUM_PARTS - 1)] += fmax(ms, 0.0) * W;                    // nsc:605
         a_rd[u & (SPHX_SUM_PARTS - 1)] += fmax(-ms, 0.0) * W;                    // nsc:606
         a_n[u & (SPHX_SUM_PARTS - 1)] += Nw * W;                                 // nsc:607
-        a_gx[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dx) + Ai * (ca * dx)) * 0.5;   // nsc:615
-        a_gy[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dy) + Ai * (ca * dy)) * 0.5;
-        a_gz[u & (SPHX_SUM_PARTS - 1)] += (Aj * (cb * dz) + Ai * (ca * dz)) * 0.5;
+        const double tg = (Aj * cb + Ai * ca) * 0.5;                                 // nsc:615 (as sphx_blob.hip density_batch)
+        a_gx[u & (SPHX_SUM_PARTS - 1)] += tg * dx;
+        a_gy[u & (SPHX_SUM_PARTS - 1)] += tg * dy;
+        a_gz[u & (SPHX_SUM_PARTS - 1)] += tg * dz;
       }
     }
     const double s_rho = parts_total(a_rho), s_rd = parts_total(a_rd), s_n = parts_total(a_n);
@@ -381,9 +382,8 @@ __global__ __launch_bounds__(256) void pass_visc_kernel(int n, int npad, int k, 
         const double qj = q0.d - r2, qi = hi2 - r2;
         const double cb = (clip && !(qj > 0.0)) ? 0.0 : -6.0 * c1 * (qj * qj);
         const double ca = ci * (qi * qi);
-        const double bx = (Bj * (cb * dx) + Bi * (ca * dx)) / 2.0;          // nsc:651
-        const double by = (Bj * (cb * dy) + Bi * (ca * dy)) / 2.0;
-        const double bz = (Bj * (cb * dz) + Bi * (ca * dz)) / 2.0;
+        const double tb = (Bj * cb + Bi * ca) / 2.0;                          // nsc:651, the common factor taken out (see pass 1)
+        const double bx = tb * dx, by = tb * dy, bz = tb * dz;
         a_x[u & (SPHX_SUM_PARTS - 1)] += bx; a_y[u & (SPHX_SUM_PARTS - 1)] += by; a_z[u & (SPHX_SUM_PARTS - 1)] += bz;
         a_h[u & (SPHX_SUM_PARTS - 1)] += bx * (qv.a - rv.a) + by * (qv.b - rv.b) + bz * (qv.c - rv.c);   // nsc:653
       }
