@@ -133,6 +133,71 @@ class OracleBackend:
             dst[:no] = torch.from_numpy(np.ascontiguousarray(src))
 
 
+class OracleFusedBackend(OracleBackend):
+    """OracleBackend + the tensor-library forms of the library's fused helpers (sphx_dev_reach_dt, sphx_dev_step_scalars,
+    sphx_dev_integrate_auto / _loop with the verdict and dt taken from device memory): with them DistributedSim takes the path
+    it takes on the GPU - the update launched before the host reads the step's scalars, the NEXT step's plan made at the end
+    of the current one - over gloo on the CPU."""
+
+    cap = 0.0
+
+    def set_reach_cap(self, cap_abs):
+        self.cap = float(cap_abs)
+
+    def _reach(self, h, vel, halo, skin, dtv):
+        speed = torch.sqrt((vel * vel).sum(dim=1))
+        if self.cap > 0.0:
+            cap = torch.full_like(h, self.cap)
+            a = torch.minimum((halo + skin - 1.0) * h, cap)
+            b = torch.minimum((halo - 1.0) * h, cap)
+            return torch.maximum(h + a, (h + b) + speed * dtv)
+        return torch.maximum((halo + skin) * h, halo * h + speed * dtv)
+
+    def reach(self, h, vel, halo_scale, skin_frac, dt_last):
+        return self._reach(h, vel, halo_scale, skin_frac, float(dt_last))
+
+    def reach_dt(self, h, vel, halo_scale, skin_frac, dt_dev):
+        return self._reach(h, vel, halo_scale, skin_frac, float(dt_dev.reshape(-1)[0]))
+
+    def plan_mask(self, pos, g_lo, g_cs, G, maps, rank):
+        lo = torch.tensor(g_lo, dtype=torch.float64)
+        c = torch.floor((pos - lo[None]) / g_cs).to(torch.int64).clamp_(0, G - 1)
+        cell = (c[:, 2] * G + c[:, 1]) * G + c[:, 0]
+        mask = maps[:, cell] != 0
+        mask[rank] = False
+        return mask, mask.sum(dim=1)
+
+    def step_scalars(self, n_owned, h, w_plan, D, hclip, ct):
+        ho = h[:n_owned]
+        bad = (ho + 2.0 * D > w_plan).any().to(torch.float64).reshape(1)
+        keep = (ho <= hclip) if hclip > 0.0 else torch.ones_like(ho, dtype=torch.bool)
+        hm = (ho * keep).sum() / keep.sum().clamp(min=1)
+        return torch.cat([bad, -ct.reshape(-1)[:1].to(torch.float64), ho.max().reshape(1), hm.reshape(1)])
+
+    def _dt(self, red2, first, fixed_dt):
+        o = self.orc
+        ct_min = -float(red2[1])
+        ctv = o.DT_0 / 10. if ct_min >= float("inf") else ct_min + 0.0001
+        return fixed_dt if fixed_dt > 0 else o.timestep(ctv, first)
+
+    def integrate_auto(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, red2, first, fixed_dt):
+        if float(red2[0]) > 0.5:                        # the halo was too thin: the state stays as it is
+            return torch.zeros(1, dtype=torch.float64)
+        dt = self._dt(red2, first, fixed_dt)
+        self.integrate(no, pos, vel, acc, E, T, m, mu, gam, ptype, ha, va, vh, dt)
+        return torch.tensor([dt], dtype=torch.float64)
+
+    def integrate_loop(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, delp, rho, va, vh, dt, red2=None, first=False,
+                       fixed_dt=0.0):
+        if red2 is None:
+            return OracleBackend.integrate_loop(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, delp, rho, va, vh, dt)
+        if float(red2[0]) > 0.5:
+            return torch.zeros(1, dtype=torch.float64)
+        dt = self._dt(red2, first, fixed_dt)
+        OracleBackend.integrate_loop(self, no, pos, vel, acc, E, T, m, mu, gam, ptype, delp, rho, va, vh, dt)
+        return torch.tensor([dt], dtype=torch.float64)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -155,7 +220,11 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, sim_kw=None):
     mine, lo, hi = mg.decompose_state(state, world, rank)
     if sim_kw.get("forms") == "loop":
         sim_kw["d"] = ics.loop_d(state, K)
-    sim = mg.DistributedSim(mine, lo, hi, OracleBackend(K), rank, world, device="cpu", **sim_kw)
+    fused = sim_kw.pop("_fused_backend", False)
+    force = sim_kw.pop("_force_replan", 0)
+    sim = mg.DistributedSim(mine, lo, hi, (OracleFusedBackend if fused else OracleBackend)(K), rank, world, device="cpu", **sim_kw)
+    if force:
+        sim.force_replan = force                     # the regime of the reference's dt rule: a new plan every step
     for _ in range(nsteps):
         sim.step()
     res = sim.owned_numpy()
@@ -163,6 +232,7 @@ def _worker(rank, world, port, n, nsteps, workload, out_dir, sim_kw=None):
         res["f_un_neighbor"] = np.ascontiguousarray(res["f_un_neighbor"].T)      # (n_owned, S): rows concatenate by rank
     res["stats"] = np.array([sim.stats["ghosts"], sim.stats["redo"], sim.stats["migrated"], sim.ex.bytes_sent,
                              sim.stats.get("replans", 0)])
+    res["ahead_ms"] = np.float64(sim.host_ms.get("plan_ahead", 0.0))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -180,6 +250,7 @@ def _run_world(world, n, nsteps, workload, tmp_path, sim_kw=None):
               if k_ in parts[0]}
     merged["dt"] = [float(p["dt"]) for p in parts]
     merged["stats"] = np.sum([p["stats"] for p in parts], axis=0)
+    merged["ahead_ms"] = [float(p["ahead_ms"]) for p in parts] if "ahead_ms" in parts[0] else None
     return merged
 
 
@@ -277,6 +348,38 @@ def test_world2_eight_steps_delayed_migration_and_forced_replans(tmp_path):
     np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
     ghosts, redo, migrated, sent, replans = got["stats"]
     assert ghosts > 0 and replans >= nsteps and migrated > 0          # (summed over the ranks)
+
+
+@pytest.mark.parametrize("forms", ["hydro_update", "loop"])
+def test_world4_plan_made_ahead_with_redo_and_migration(tmp_path, forms):
+    """The path the GPU driver takes by default, on four ranks over gloo (ADVICE, round 2: it had only run with two ranks
+    sharing one GPU): the update launched before the host reads the step's scalars (verdict and dt 'on the device'), the
+    NEXT step's plan - reach, need map, both all_gathers, send mask - made at the end of the current one while deferred
+    exchanges may still be in flight, every step a replan (force_replan), no head-room in the claims so that some steps are
+    REDONE (a redo drops the plan made ahead), particles migrating on every 2nd replan inside that window.  The result
+    is still the single-domain oracle's."""
+    from oracle import sph_oracle as orc
+    import sph_code_amd.ics as ics
+    n, nsteps = 3000, 6
+    wl = "uniform_cube" if forms == "loop" else "polytrope"      # (quiet for the six steps: no runaway particle to compare)
+    kw = dict(_fused_backend=True, _force_replan=64, halo_scale=1.0, skin_frac=0.0, migrate_every=2)
+    if forms == "loop":
+        kw["forms"] = "loop"
+    got = _run_world(4, n, nsteps, wl, tmp_path, sim_kw=kw)
+    ghosts, redo, migrated, sent, replans = got["stats"]
+    assert redo > 0 and migrated > 0 and replans >= 4 * nsteps
+    assert all(t > 0.0 for t in got["ahead_ms"])                    # every rank did make plans ahead
+    if forms == "loop":
+        ref = ics.uniform_cube(n, light=True)
+        d = ics.loop_d(ref, K)
+        for it in range(nsteps):
+            ref = orc.step_loop(ref, d, n_neigh=K, eps=0.0, first=(it == 0))
+    else:
+        ref = _reference(n, nsteps, wl)
+    np.testing.assert_allclose(got["sizes"], ref["sizes"], rtol=1e-13)
+    np.testing.assert_allclose(got["points"], ref["points"], rtol=1e-12)
+    np.testing.assert_allclose(got["densities"], ref["densities"], rtol=1e-12)
+    assert len(set(got["dt"])) == 1 and got["dt"][0] == pytest.approx(ref["dt"], rel=1e-14)
 
 
 def test_world2_halo_too_thin_is_detected_and_redone(tmp_path):
