@@ -253,12 +253,19 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
         const bool q_out = (LIST || OUTL || a.distrust) && sphx_outside_box(g, xi, yi, zi);
         const double R_given = R;
         bool far_counted = false;
-#ifdef SPHX_KNN_PROF
-        const long long prof_t0 = clock64();
-        const u64 prof_c0 = ncand;
-        int prof_cat = q_out ? 3 : 0;
-        u64 q_sec[4] = {0, 0, 0, 0};
-#endif
+        // which outlier levels hold anything at all (one round trip per far query: lane l asks for level l + 1): an escaper's
+        // sphere reaches most of the 18-20 levels, nearly all of them empty - 1024 rows each to test, per rung of its ladder.
+        // (Measured and dropped: with few outliers in all, ONE pass with an unbounded radius instead of the ladder - fewer
+        // retries, the same time: the ladder is not what a far query's 0.5 ms are made of.)
+        u64 occm = ~0ull;
+        if (OUTL && q_out) {
+            int c_lv = 0;
+            if (lane < a.ol.L) {
+                const int* stl = a.ol.start + (size_t)lane * (OLEV_N * OLEV_N * OLEV_N);
+                c_lv = stl[OLEV_N * OLEV_N * OLEV_N] - stl[0];
+            }
+            occm = __builtin_amdgcn_ballot_w64(c_lv > 0);
+        }
         // A stale hint: the particle has moved (a diverging run moves it by several h per step) into a neighbourhood far
         // denser than its previous radius implies - the 3x3x3 block of cells around it alone holds many times what a sphere
         // of that radius should.  The hinted sphere would then cover thousands of times the candidates needed (the whole
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             const int cz1 = (int)fminf(fmaxf(fz + Rc, 0.0f), nz1);
             const int ysp = cy1 - cy0 + 1;
             int nrows = __mul24(ysp, cz1 - cz0 + 1);
+            if (indirect && !((occm >> (lv - 1)) & 1ull)) nrows = 0;      // an empty level
             if (finite) {
                 const float ex = fmaxf(fmaxf(-fx, fx - (nx1 + 1.0f)), 0.0f), ey = fmaxf(fmaxf(-fy, fy - (ny1 + 1.0f)), 0.0f),
                             ez = fmaxf(fmaxf(-fz, fz - (nz1 + 1.0f)), 0.0f);
