@@ -266,6 +266,12 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             }
             occm = __builtin_amdgcn_ballot_w64(c_lv > 0);
         }
+#ifdef SPHX_KNN_PROF
+        const long long prof_t0 = clock64();
+        const u64 prof_c0 = ncand;
+        int prof_cat = q_out ? 3 : 0;
+        u64 q_sec[4] = {0, 0, 0, 0};
+#endif
         // A stale hint: the particle has moved (a diverging run moves it by several h per step) into a neighbourhood far
         // denser than its previous radius implies - the 3x3x3 block of cells around it alone holds many times what a sphere
         // of that radius should.  The hinted sphere would then cover thousands of times the candidates needed (the whole
