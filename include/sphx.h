@@ -86,6 +86,8 @@ typedef struct sphx_stats {
     int64_t bad_energy;    /* E or heat x dt NaN or inf before the nan_to_num of drv:490                                    */
     int64_t bad_state;     /* updated position or velocity NaN or inf (the next step's clamp, drv:233-238, catches them)    */
     int64_t bad_h;         /* kNN radius 0 (coincident points), NaN or inf                                                  */
+    int64_t graph_steps;   /* of `steps`: replays of a captured step graph (launch-bound sizes; SPHX_GRAPH)      */
+    int64_t search_steps;  /* steps accumulated in ms_search (replayed steps carry no timing events)                         */
 } sphx_stats;
 
 /* ---- context ----------------------------------------------------------------------- */

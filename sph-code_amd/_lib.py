@@ -25,7 +25,7 @@ class SphxStats(C.Structure):
                [("cell_size", C.c_double), ("ms_gravity", C.c_double), ("fallback_queries", C.c_int64),
                 ("ms_species", C.c_double), ("short_rows", C.c_int64), ("detail_steps", C.c_int64), ("far_queries", C.c_int64),
                 ("outlier_levels", C.c_int64), ("bad_accel", C.c_int64), ("bad_energy", C.c_int64), ("bad_state", C.c_int64),
-                ("bad_h", C.c_int64)]
+                ("bad_h", C.c_int64), ("graph_steps", C.c_int64), ("search_steps", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

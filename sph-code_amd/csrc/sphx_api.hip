@@ -19,8 +19,11 @@ int sphx_ensure(sphx_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 8;
     if (b.cap >= bytes) return SPHX_OK;
     if (b.p) {
+        if (ctx->capturing) return sphx_set_err(ctx, SPHX_E_STATE, "a buffer would have to grow while a step is being captured");
+        sphx_graph_drop(ctx);                  // (a recorded step holds the old address)
         // buffers may still be referenced by queued work
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        sphx_graph_reap(ctx);
         HIPCHK(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -134,6 +137,9 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = env("SPHX_GRAV_WS")) { int v = atoi(e); if (v >= 1 && v <= 4) ctx->grav_ws = v; }
     if (const char* e = env("SPHX_LDS")) ctx->use_lds = atoi(e) != 0;
     if (const char* e = env("SPHX_BLOB_SLOTS")) ctx->blob_slots = atoi(e);
+    if (const char* e = env("SPHX_GRAPH")) ctx->graph_mode = atoi(e);           // 0 never, 1 always, 2 for n <= SPHX_GRAPH_MAX_N
+    if (const char* e = env("SPHX_GRAPH_MAX_N")) ctx->graph_max_n = atoll(e);
+    if (const char* e = env("SPHX_GRAPH_EPOCH")) { int v = atoi(e); if (v >= 2) ctx->graph_epoch = v; }
     if (const char* e = env("SPHX_BLOB_WGS")) {      // workgroups per CU of the LDS passes' persistent grid
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -193,6 +199,8 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    sphx_graph_drop(ctx);
+    sphx_graph_reap(ctx);
     DevBuf* all[] = {&ctx->rec1, &ctx->recv, &ctx->nbr, &ctx->rho, &ctx->rhod, &ctx->nden, &ctx->G,
                      &ctx->Pi, &ctx->Bw, &ctx->rho_s, &ctx->bc_s, &ctx->self_s, &ctx->drag_on, &ctx->drag_re, &ctx->grav, &ctx->grav_sort, &ctx->grav_tmp, &ctx->grav_pyr, &ctx->grav_cell, &ctx->lrec_a, &ctx->lrec_v, &ctx->porder, &ctx->mcount, &ctx->mstart, &ctx->slot16, &ctx->uniq, &ctx->list64, &ctx->dref, &ctx->pos0, &ctx->pos4, &ctx->va, &ctx->vh, &ctx->ha, &ctx->F,
                      &ctx->scal, &ctx->cell_of, &ctx->cell_start, &ctx->cell_fill, &ctx->perm,
@@ -201,7 +209,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->Tprev, &ctx->badc};
+                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->badc};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);
@@ -229,11 +237,13 @@ extern "C" const char* sphx_last_error(const sphx_ctx* ctx) { return ctx ? ctx->
 
 extern "C" int sphx_set_constants(sphx_ctx* ctx, const sphx_constants* c) {
     if (!ctx || !c) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     ctx->cst = *c;
     return SPHX_OK;
 }
 extern "C" int sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     if (rscale > 0.0) {
         if (rscale < 1.0) return sphx_set_err(ctx, SPHX_E_ARG, "rscale %g < 1", rscale);
         ctx->rscale = rscale;
@@ -243,6 +253,7 @@ extern "C" int sphx_set_tuning(sphx_ctx* ctx, double rscale, double cell_factor)
 }
 extern "C" int sphx_set_incremental(sphx_ctx* ctx, int verlet, double rscale_build) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     ctx->use_verlet = verlet != 0;
     if (!ctx->use_verlet) ctx->list_valid = false;
     if (rscale_build > 0.0) {
@@ -448,6 +459,8 @@ extern "C" int sphx_state_upload(sphx_ctx* ctx, int64_t n, int s, const double* 
     ctx->h_clip = 0.0;
     ctx->lag_bvalid[0] = ctx->lag_bvalid[1] = ctx->lag_hvalid[0] = ctx->lag_hvalid[1] = false;
     ctx->step_count = 0;
+    ctx->tprev_valid = false;
+    sphx_graph_drop(ctx);
     ctx->dt_last = 0.0;
     return SPHX_OK;
 }
@@ -470,6 +483,7 @@ extern "C" int sphx_state_set_drag(sphx_ctx* ctx, const double* mean_grain_mass,
 
 extern "C" int sphx_state_set_loop_forms(sphx_ctx* ctx, int on, double d) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_loop_forms before sphx_state_upload");
     if (on && !(d > 0.0)) return sphx_set_err(ctx, SPHX_E_ARG, "the loop forms need the driver's global d > 0 (drv:68)");
     if (on && ctx->use_verlet) return sphx_set_err(ctx, SPHX_E_STATE, "loop-form steps are not combined with incremental search");
@@ -480,6 +494,7 @@ extern "C" int sphx_state_set_loop_forms(sphx_ctx* ctx, int on, double d) {
 
 extern "C" int sphx_set_gravity_order(sphx_ctx* ctx, int order) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     if (order != 1 && order != 2) return sphx_set_err(ctx, SPHX_E_ARG, "gravity order %d not 1 (monopole) or 2 (quadrupole)", order);
     ctx->grav_order = order;
     return SPHX_OK;
@@ -487,12 +502,14 @@ extern "C" int sphx_set_gravity_order(sphx_ctx* ctx, int order) {
 
 extern "C" int sphx_set_clip_grad(sphx_ctx* ctx, int on) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     ctx->clip_grad = on ? 1 : 0;
     return SPHX_OK;
 }
 
 extern "C" int sphx_state_set_gravity(sphx_ctx* ctx, int mode, double G) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_state_set_gravity before sphx_state_upload");
     if (mode < 0 || mode > 2) return sphx_set_err(ctx, SPHX_E_ARG, "gravity mode %d not in {0, 1, 2}", mode);
     if (mode == 2 && ctx->use_verlet)
@@ -510,12 +527,14 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     // Timing events: around the step and around the search always (the bench's roofline needs the search's launch time);
     // one per pass only on request (sphx_set_timing_detail / SPHX_TIMING_DETAIL=1) - an event record between two
     // dependent kernels costs the stream ~10 us, six of them 4 % of a 1.5 ms step.
-    const bool detail = ctx->timing_detail;
+    const bool cap = ctx->capturing;         // recorded into a step graph, not run: nothing here may wait, read back or time
+    const bool detail = ctx->timing_detail && !cap;
     ctx->ev_detail[ring] = detail;
     // (the step's own start and end events likewise: without them the call's first and last step bracket the call,
     //  whose time is then shared out over its steps)
-    const bool rec0 = detail || call_first, rec7 = detail || call_last;
+    const bool rec0 = (detail || call_first) && !cap, rec7 = (detail || call_last) && !cap;
     ctx->ev_has07[ring] = (rec0 ? 1 : 0) | (rec7 ? 2 : 0);
+    if (!cap) ctx->replay_ok = false;        // (set at the end of a real step that a replay may freeze)
     ctx->map_perm = nullptr;
     ctx->qorder = nullptr;
     ctx->blob_lists = false;
@@ -537,6 +556,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     bool searched = false;
     if (ctx->use_verlet && ctx->list_valid && ctx->list_n == n && ctx->list_k == k) {
         StateArrays& r = ctx->st;
+        if (cap) return sphx_set_err(ctx, SPHX_E_STATE, "a Verlet step cannot be captured");
         HIPCHK(hipEventRecord(ev[1], ctx->stream));
         int64_t nfail = 0;
         SPHX_TRY(sphx_knn_refresh(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(),
@@ -551,7 +571,10 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     if (!searched) {
         // cell size from the previous step's mean h (read back together with the bounding box)
         double cell_hint = 0.0;
-        if (ctx->step_count > 0) {
+        if (cap) {                            // the real step's figures, frozen
+            cell_hint = ctx->cap_cell_hint;
+            ctx->h_clip = ctx->cap_h_clip;
+        } else if (ctx->step_count > 0) {
             const double* hs;                                                  // [0] sum ... [3] count
             if (ctx->lag_hvalid[ctx->lag_hslot]) {
                 // copied out right after the previous step's search: no wait on that step's tail
@@ -578,15 +601,19 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
                 cell_hint = ctx->cell_factor * sphx_cell_feedback(ctx, n) * hmean;
                 ctx->h_clip = ctx->h_clip_factor * hmean;
             }
+            ctx->cap_cell_hint = cell_hint;
+            ctx->cap_h_clip = ctx->h_clip;
         }
         {
             StateArrays& r = ctx->st;       // the box statistics are the previous step's when there are any
             const bool blob = ctx->use_blob && !ctx->use_verlet;
             ctx->lag_on = true;
-            ctx->step_ev1 = ev[1];            // (recorded below, behind the state's permutation)
+            ctx->in_fused_step = true;
+            ctx->step_ev1 = cap ? nullptr : ev[1];            // (recorded below, behind the state's permutation)
             ctx->defer_cell_sort = blob;      // the blob-order pass over the cells sorts their members too
             const int rc_ = sphx_build_grid(ctx, n, k, r.x.as<double>(), r.y.as<double>(), r.z.as<double>(), cell_hint);
             ctx->lag_on = false;
+            ctx->in_fused_step = false;
             ctx->step_ev1 = nullptr;
             ctx->defer_cell_sort = false;
             ctx->clamp_vx = nullptr;
@@ -601,7 +628,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
             }
         }
         const bool split_perm = ctx->split_perm && ctx->side_stream && !ctx->use_verlet;
-        SPHX_TRY(sphx_permute_state(ctx, n, split_perm, ev[1]));      // (records ev[1] behind the search's part)
+        SPHX_TRY(sphx_permute_state(ctx, n, split_perm, cap ? nullptr : ev[1]));      // (records ev[1] behind the search's part)
         StateArrays& r = ctx->st;
         KnnOut o;
         o.nbr = ctx->nbr.as<int>();
@@ -632,14 +659,15 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         ctx->stats.rebuild_steps++;
     }
     StateArrays& s = ctx->st;
-    HIPCHK(hipEventRecord(ev[2], ctx->stream));
+    hipEvent_t ev_search_end = cap ? ctx->ev_fork : ev[2];       // (a timing event is not recorded into a graph)
+    HIPCHK(hipEventRecord(ev_search_end, ctx->stream));
     // the record build (bandwidth-bound) does not depend on the list dedup (latency-bound): side by side - and with
     // it the sum of h and its copy to the host (the next step's cell size, read there when the next grid is sized;
     // the search's counters travel in the same copy: SC_HSUM .. SC_BADHINT are consecutive slots)
     const bool fork = ctx->qorder && ctx->use_lds && !ctx->loop_forms && ctx->side_stream;
     hipStream_t hs_stream = ctx->stream;
     if (fork) {
-        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ev[2], 0));       // (the search's end event doubles as the fork)
+        HIPCHK(hipStreamWaitEvent(ctx->side_stream, ev_search_end, 0));       // (the search's end event doubles as the fork)
         hs_stream = ctx->side_stream;
     }
     // (forked: BEHIND the record build on the side stream - the passes wait for that one, not for this; nobody but the
@@ -650,6 +678,7 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         const int rc_h = sphx_hsum(ctx, n, s.hprev.as<double>());
         ctx->stream = main_stream;
         SPHX_TRY(rc_h);
+        if (cap) return SPHX_OK;              // (the sums stay on the device: the next REAL step reads them, with a wait)
         const int hsl = ctx->lag_hslot ^ 1;
         HIPCHK(hipMemcpyAsync((char*)ctx->pinned + LAG_OFF + 512 * hsl + 256, ctx->scal.as<double>() + SC_HSUM,
                               (SC_KGDBG + 2 - SC_HSUM + 1) * sizeof(double), hipMemcpyDeviceToHost, hs_stream));
@@ -689,9 +718,10 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
         ctx->stream = main_stream;
         if (rc_prep != SPHX_OK) return rc_prep;
         if (fork) {
+            if (cap) SPHX_TRY(h_sums_out());          // (inside the fork: a captured side stream must rejoin with nothing behind)
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            SPHX_TRY(h_sums_out());
+            if (!cap) SPHX_TRY(h_sums_out());
         }
     }
     if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
@@ -729,6 +759,13 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     SPHX_TRY(sphx_integrate(ctx, n, 1, first, fixed_dt));
     if (rec7) HIPCHK(hipEventRecord(ev[7], ctx->stream));
     ctx->step_count++;
+    // May the next steps be replays of this one's decisions?  A hinted step on the fused grid build, nothing that decides
+    // on the host from this step's own results (Verlet refresh, outlier levels, hint distrust, the drag's scatter plan,
+    // gravity's sort) and no per-pass timing.
+    if (!cap)
+        ctx->replay_ok = searched == false && !first && ctx->step_count >= 2 && ctx->grid_fused && !ctx->use_verlet && ctx->olev.L == 0 &&
+                         !ctx->distrust && !ctx->drag && !ctx->gravity && !(ctx->s > 0 && ctx->fun_id.p) && !ctx->timing_detail && ctx->use_blob && ctx->use_group &&
+                         ctx->side_stream != nullptr;
     return SPHX_OK;
 }
 
@@ -743,6 +780,7 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
     HIPCHK(hipEventElapsedTime(&ms[1], ev[1], ev[2]));
     st.ms_search += ms[1];
     st.steps += 1;
+    st.search_steps += 1;
     st.n = ctx->n;
     if (!ctx->ev_detail[ring]) return SPHX_OK;    // (only the search's events were recorded for this step; ms_total: per call)
     float tot;
@@ -768,6 +806,76 @@ static int collect_stats(sphx_ctx* ctx, int ring) {
     return SPHX_OK;
 }
 
+// ---- step graphs (see sphx_internal.h) --------------------------------------------------------------------------
+// (an executable graph may still be RUNNING when the host decides to forget it - the loop runs ahead of the GPU - so it
+//  is only retired here and destroyed behind the next wait for the stream: sphx_graph_reap)
+void sphx_graph_drop(sphx_ctx* ctx) {
+    for (int p = 0; p < 2; ++p) {
+        if (!ctx->gexec[p]) continue;
+        if (ctx->n_retired == (int)(sizeof(ctx->retired) / sizeof(ctx->retired[0]))) {
+            (void)hipStreamSynchronize(ctx->stream);
+            sphx_graph_reap(ctx);
+        }
+        ctx->retired[ctx->n_retired++] = ctx->gexec[p];
+        ctx->gexec[p] = nullptr;
+    }
+    ctx->graph_left = 0;
+}
+void sphx_graph_reap(sphx_ctx* ctx) {          // the stream has been waited for: nothing retired can still be running
+    for (int q = 0; q < ctx->n_retired; ++q) (void)hipGraphExecDestroy(ctx->retired[q]);
+    ctx->n_retired = 0;
+}
+
+// what a replayed step does to the HOST's view of the state: the permutation swaps the two sets of arrays, the update
+// swaps the temperature buffers back (sphx_permute_state, sphx_integrate)
+static void graph_host_side(sphx_ctx* ctx) {
+    StateArrays t = ctx->st; ctx->st = ctx->alt; ctx->alt = t;
+    DevBuf tt = ctx->st.T; ctx->st.T = ctx->alt.T; ctx->alt.T = tt;
+    ctx->tprev_valid = true;
+    ctx->step_count++;
+    ctx->stats.rebuild_steps++;
+    ctx->stats.graph_steps++;
+    ctx->stats.steps++;
+}
+
+// Record one step into a graph (nothing runs), instantiate it for the current parity and launch it.  On any failure the
+// host's view is put back, graphs are switched off for this context and the caller runs the step the ordinary way.
+static int capture_and_launch(sphx_ctx* ctx, int k, double dist, double fixed_dt, bool* done) {
+    *done = false;
+    const int par = (int)(ctx->step_count & 1);
+    const StateArrays st0 = ctx->st, alt0 = ctx->alt;
+    const int64_t sc0 = ctx->step_count;
+    const bool tp0 = ctx->tprev_valid;
+    const sphx_stats stats0 = ctx->stats;
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->graph_mode = 0;
+        return SPHX_OK;
+    }
+    ctx->capturing = true;
+    const int rc = one_step(ctx, k, dist, 0, fixed_dt, false, false);
+    ctx->capturing = false;
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);
+    hipGraphExec_t ge = nullptr;
+    hipError_t e_inst = hipErrorUnknown;
+    if (rc == SPHX_OK && e_end == hipSuccess && g) e_inst = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (rc != SPHX_OK || e_end != hipSuccess || e_inst != hipSuccess || !ge) {
+        (void)hipGetLastError();
+        ctx->st = st0; ctx->alt = alt0; ctx->step_count = sc0; ctx->tprev_valid = tp0; ctx->stats = stats0;
+        ctx->graph_mode = 0;                       // (this runtime / this state cannot be captured: the ordinary way from here on)
+        sphx_graph_drop(ctx);
+        return SPHX_OK;
+    }
+    ctx->gexec[par] = ge;
+    ctx->stats.graph_steps++;
+    ctx->stats.steps++;
+    HIPCHK(hipGraphLaunch(ge, ctx->stream));
+    *done = true;
+    return SPHX_OK;
+}
+
 extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int first, double fixed_dt) {
     if (!ctx) return SPHX_E_ARG;
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "sphx_step before sphx_state_upload");
@@ -776,23 +884,48 @@ extern "C" int sphx_step(sphx_ctx* ctx, int nsteps, int k, double dist, int firs
     HIPCHK(hipSetDevice(ctx->device));
     if (!(dist > 0.0) || !isfinite(dist)) dist = 0.0;
     ctx->k = k;
-    hipEvent_t call_start = nullptr, call_end = nullptr;
     const bool per_call = !ctx->timing_detail;             // (else every step times itself)
+    // the call's wall time on the stream, over all its steps (events of its own: a replayed step records none)
+    if (per_call) HIPCHK(hipEventRecord(ctx->ev[8], ctx->stream));
+    const bool graphs = (ctx->graph_mode == 1 || (ctx->graph_mode == 2 && ctx->n <= ctx->graph_max_n)) && ctx->stream == ctx->own_stream;
+    if (ctx->gexec[0] || ctx->gexec[1])
+        if (!graphs || k != ctx->graph_k || dist != ctx->graph_dist || fixed_dt != ctx->graph_fixed_dt) sphx_graph_drop(ctx);
     for (int it = 0; it < nsteps; ++it) {
+        const int par = (int)(ctx->step_count & 1);
+        if (graphs && !(first && it == 0) && ctx->graph_left > 0) {
+            if (ctx->gexec[par]) {                                  // replay
+                HIPCHK(hipGraphLaunch(ctx->gexec[par], ctx->stream));
+                graph_host_side(ctx);
+                if (--ctx->graph_left == 0) sphx_graph_drop(ctx);
+                continue;
+            }
+            bool done = false;                                      // the epoch's other parity: record it now
+            SPHX_TRY(capture_and_launch(ctx, k, dist, fixed_dt, &done));
+            if (done) {
+                if (--ctx->graph_left == 0) sphx_graph_drop(ctx);
+                continue;
+            }
+        }
+        // an ordinary step: sizes the grid and takes the search's decisions from the lagged read-backs
+        sphx_graph_drop(ctx);
         const int ring = (int)(ctx->step_count % 3);
         SPHX_TRY(collect_stats(ctx, ring));            // (the step launched three steps ago, if still uncollected)
-        if (it == 0) call_start = ctx->evring[ring][0];
-        if (it == nsteps - 1) call_end = ctx->evring[ring][7];
-        SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt, it == 0, it == nsteps - 1));
+        SPHX_TRY(one_step(ctx, k, dist, first && it == 0, fixed_dt, false, false));
         ctx->ev_pending |= 1u << ring;
         SPHX_TRY(collect_stats(ctx, (ring + 1) % 3));  // two steps ago: finished long since, no wait
+        if (graphs && ctx->replay_ok) {                 // the next graph_epoch steps replay this one's decisions
+            ctx->graph_left = ctx->graph_epoch;
+            ctx->graph_k = k; ctx->graph_dist = dist; ctx->graph_fixed_dt = fixed_dt;
+        }
     }
+    if (per_call) HIPCHK(hipEventRecord(ctx->ev[9], ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->scal.p, SC_NSLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    sphx_graph_reap(ctx);
     for (int r = 0; r < 3; ++r) SPHX_TRY(collect_stats(ctx, (int)((ctx->step_count + r) % 3)));   // oldest first
-    if (per_call && call_start && call_end) {              // the call's wall time on the stream, over all its steps
+    if (per_call) {                                        // the call's wall time on the stream, over all its steps
         float tot = 0.f;
-        HIPCHK(hipEventElapsedTime(&tot, call_start, call_end));
+        HIPCHK(hipEventElapsedTime(&tot, ctx->ev[8], ctx->ev[9]));
         ctx->stats.ms_total += tot;
     }
     const u64* sc = (const u64*)ctx->pinned;
@@ -871,6 +1004,7 @@ extern "C" int sphx_state_download(sphx_ctx* ctx, double* pos, double* vel, doub
 int sphx_agb_table_set(sphx_ctx* ctx, int S, int nspl, const int32_t* ntx, const int32_t* nty, const double* tx, const double* ty,
                        const double* coeffs, const int32_t* mapto, double divisor, const double* mu_specie, double solar_mass) {
     ctx->agb_on = false;
+    sphx_graph_drop(ctx);
     if (nspl == 0) return SPHX_OK;
     if (S < 7 || S > AGB_MAX_SPEC) return sphx_set_err(ctx, SPHX_E_ARG, "AGB table: %d species (7..%d)", S, AGB_MAX_SPEC);
     if (!ntx || !nty || !tx || !ty || !coeffs || !mapto || !mu_specie)
@@ -995,6 +1129,7 @@ extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
 }
 extern "C" int sphx_set_timing_detail(sphx_ctx* ctx, int on) {
     if (!ctx) return SPHX_E_ARG;
+    sphx_graph_drop(ctx);
     ctx->timing_detail = on != 0;
     return SPHX_OK;
 }

@@ -60,6 +60,7 @@ int sphx_dev_collect(sphx_ctx* ctx) {
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
     ctx->stats.ms_search += ms;
     ctx->stats.steps += 1;
+    ctx->stats.search_steps += 1;
     ctx->stats.n = ctx->map_nactive;
     return SPHX_OK;
 }

@@ -433,7 +433,16 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     for (int c = 0; c < 3; ++c) { clip0.lo[c] = ctx->clip_lo[c]; clip0.hi[c] = ctx->clip_hi[c]; }
     bool fused = false;           // this step's statistics come out of the cell-count kernel itself
     int lag_cur = 0;
-    if (ctx->lag_on) {
+    ctx->grid_fused = false;
+    if (!ctx->in_fused_step) sphx_graph_drop(ctx);      // (an array call or the device API between the loop's steps: its grid, its box statistics)
+    if (ctx->capturing) {
+        // recorded into a step graph: the box statistics the last real step sized its grid from, no host wait; this step's
+        // own statistics still come out of the count kernel (tbox, on the device), but are not copied out
+        if (!ctx->lag_on || !ctx->fuse_count) return sphx_set_err(ctx, SPHX_E_STATE, "only the fused loop's grid build can be captured");
+        for (int q = 0; q < 13; ++q) bb[q] = ctx->cap_bb[q];
+        fused = true;
+        ctx->grid_fused = true;
+    } else if (ctx->lag_on) {
         // Fused step loop: this step's statistics are launched and copied out, the grid is sized from
         // the previous step's (already on the host) - the loop never waits for the step it launches.
         // One step of motion makes the box slightly stale, which only steers performance: particles
@@ -458,14 +467,18 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         ctx->lag_bvalid[cur] = true;
         ctx->lag_bn[cur] = n;
         ctx->lag_bslot = cur;
+        ctx->grid_fused = fused;
     } else {
         if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
         SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, true));
     }
-    if (ctx->clip_valid && bb[12] < 0.5 * (double)n) {     // the clip box lost the cloud: re-anchor
+    if (!ctx->capturing && ctx->clip_valid && bb[12] < 0.5 * (double)n) {     // the clip box lost the cloud: re-anchor
         if (ctx->clamp_vx) { SPHX_TRY(sphx_clamp(ctx, n, ctx->st)); ctx->clamp_vx = nullptr; }
         SPHX_TRY(sphx_bbox(ctx, n, x, y, z, bb, false));
+        ctx->grid_fused = false;                // (a host wait: not a step to replay)
     }
+    if (!ctx->capturing)
+        for (int q = 0; q < 13; ++q) ctx->cap_bb[q] = bb[q];     // (what a captured step sizes its grid from)
     double tmin[3], tmax[3];
     for (int c = 0; c < 3; ++c) {
         if (!(bb[3 + c] >= bb[c])) { bb[c] = 0.0; bb[3 + c] = 0.0; }   // no finite coordinate
@@ -597,7 +610,7 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc));
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
                        ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out);
-    if (bb_fold_out) {
+    if (bb_fold_out && !ctx->capturing) {
         char* slot = (char*)ctx->pinned + LAG_OFF;
         HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, bb_fold_out, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->step_ev1) {

@@ -329,8 +329,8 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixe
     a.x = s.x.as<double>(); a.y = s.y.as<double>(); a.z = s.z.as<double>();
     a.vx = s.vx.as<double>(); a.vy = s.vy.as<double>(); a.vz = s.vz.as<double>();
     a.ax = s.ax.as<double>(); a.ay = s.ay.as<double>(); a.az = s.az.as<double>();
-    SPHX_TRY(sphx_ensure(ctx, ctx->Tprev, (size_t)n * sizeof(double)));
-    a.E = s.E.as<double>(); a.T = ctx->Tprev.as<double>();      // (the kernel never reads T: written elsewhere, swapped below)
+    SPHX_TRY(sphx_ensure(ctx, ctx->alt.T, (size_t)n * sizeof(double)));
+    a.E = s.E.as<double>(); a.T = ctx->alt.T.as<double>();      // (the kernel never reads T: written elsewhere, swapped below)
     a.m = s.m.as<double>(); a.mu = s.mu.as<double>(); a.gam = s.gam.as<double>();
     a.ptype = s.ptype.as<double>();
     a.ha = ctx->ha.as<double>(); a.va = ctx->va.as<double>(); a.vh = ctx->vh.as<double>();
@@ -345,7 +345,8 @@ int sphx_integrate(sphx_ctx* ctx, int64_t n, int fold_dt, int first, double fixe
     a.counters = ctx->badc.as<u64>();
     hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a);
     HIPCHK(hipGetLastError());
-    { DevBuf t = s.T; s.T = ctx->Tprev; ctx->Tprev = t; }       // st.T: the new temperatures; Tprev: those the sums read
+    { DevBuf t = s.T; s.T = ctx->alt.T; ctx->alt.T = t; }       // st.T: the new temperatures; alt.T: those the sums read
+    ctx->tprev_valid = true;
     return SPHX_OK;
 }
 
@@ -361,10 +362,10 @@ extern "C" int sphx_state_download_pressure(sphx_ctx* ctx, double* pressure) {
     if (!ctx->has_state) return sphx_set_err(ctx, SPHX_E_STATE, "no state uploaded");
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = ctx->n;
-    if (ctx->step_count < 1 || !ctx->Tprev.p) { memset(pressure, 0, (size_t)n * sizeof(double)); return SPHX_OK; }
+    if (ctx->step_count < 1 || !ctx->tprev_valid || !ctx->alt.T.p) { memset(pressure, 0, (size_t)n * sizeof(double)); return SPHX_OK; }
     SPHX_TRY(sphx_ensure(ctx, ctx->out_a, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(pressure_by_id, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->st.id.as<int>(), ctx->nden.as<double>(), ctx->Tprev.as<double>(), ctx->cst.k_B, ctx->out_a.as<double>());
+                       ctx->st.id.as<int>(), ctx->nden.as<double>(), ctx->alt.T.as<double>(), ctx->cst.k_B, ctx->out_a.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(pressure, ctx->out_a.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

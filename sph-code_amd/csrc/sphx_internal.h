@@ -284,10 +284,33 @@ struct sphx_ctx {
     DevBuf idx64, dist_out, nontriv, h_api;
     // ---- simulation state ----
     StateArrays st, alt;
-    // The update writes the new temperatures into this buffer and swaps it with st.T: what is left here is T at the instant
-    // of the step's sums, in the step's sorted order like rho / nden - P_i = n_i k_B T_i of ONE instant at no cost to the
-    // step (sphx_state_download_pressure)
-    DevBuf Tprev;
+    // The update writes the new temperatures into alt.T (dead once the state has been permuted) and swaps it with st.T:
+    // what is left in alt.T is T at the instant of the step's sums, in the step's sorted order like rho / nden - P_i = n_i
+    // k_B T_i of ONE instant at no cost to the step (sphx_state_download_pressure).  (st.T and alt.T are then the same two
+    // buffers at the start of every step; the other arrays of st / alt swap roles every step: period 2, which the step
+    // graphs below rely on.)
+    bool tprev_valid = false;
+    // ---- step graphs (sphx_api.hip sphx_step): the launch-bound sizes.  A quiet step's ~25 launches replayed as a hipGraph
+    // cost half the launch overhead of the stream (tools/graphrate.hip: 25 dependent small kernels 100 -> 50 us).  One REAL
+    // step sizes the grid and takes the search's decisions from the lagged read-backs as always; the next two steps are
+    // CAPTURED with those decisions frozen (one per parity of the double-buffered state) and then replayed alternately for
+    // up to graph_epoch steps - the grid box and cell size only steer performance (out-of-box particles are clamped into the
+    // boundary cells, which the search handles exactly), and every replayed step still computes its own true bounding box on
+    // the device.  Frozen too: the list-mode launch's grid, no outlier levels (a state that needs them is not replayed).
+    int graph_mode = 0;                 // SPHX_GRAPH: 0 never (default: measured slower), 1 whenever a step can be replayed, 2 for n <= graph_max_n
+    int64_t graph_max_n = 200000;       // SPHX_GRAPH_MAX_N
+    int graph_epoch = 64;               // SPHX_GRAPH_EPOCH: replays between two real steps
+    bool in_fused_step = false;         // sphx_build_grid is being called by the fused loop's step (any other grid build drops the graphs)
+    bool grid_fused = false;            // the last grid build took its statistics from the fused count kernel (no host wait)
+    bool capturing = false;             // one_step is being recorded, not run: no host waits, no timing events, no read-backs
+    bool replay_ok = false;             // the last real step left decisions a replay may freeze (hinted, fused, no levels ...)
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};      // by parity of step_count
+    hipGraphExec_t retired[16] = {nullptr};            // forgotten, possibly still running: destroyed behind the next stream wait
+    int n_retired = 0;
+    int graph_k = 0; double graph_dist = 0.0, graph_fixed_dt = 0.0;     // the sphx_step arguments the graphs were captured with
+    int graph_left = 0;                 // replays left in this epoch
+    double cap_bb[13] = {0}, cap_cell_hint = 0.0, cap_h_clip = 0.0;   // what the real step read from the lagged slots
+    int64_t graph_steps = 0;            // steps that were replays (statistics)
     DevBuf badc;                  // failure counters, BADC_BUCKETS x BADC_STRIDE u64 (zeroed at sphx_create / sphx_reset_stats)
     bool has_state = false;
     int64_t step_count = 0;
@@ -332,6 +355,8 @@ struct sphx_ctx {
 };
 
 int sphx_set_err(sphx_ctx* ctx, int code, const char* fmt, ...);
+void sphx_graph_drop(sphx_ctx* ctx);      // forget the step graphs (new state, other step mode ...)
+void sphx_graph_reap(sphx_ctx* ctx);      // ... and destroy them, once the stream has been waited for
 int sphx_ensure(sphx_ctx* ctx, DevBuf& b, size_t bytes);
 
 #define HIPCHK(expr)                                                                         \

@@ -848,7 +848,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
         // (the fused loop copies these slots out together with its mean-h read-back and hands them over: knn_lag_*)
         const bool lagged = ctx->olev_mode == 2 || ctx->distrust_mode == 2;
         const bool ext = ctx->knn_lag_external;
-        if (lagged && (ext ? ctx->knn_lag_valid : ctx->olev_ev_valid)) {
+        if (!ctx->capturing && lagged && (ext ? ctx->knn_lag_valid : ctx->olev_ev_valid)) {
             if (!ext) HIPCHK(hipEventSynchronize(ctx->olev_ev));
             const u64* v = ext ? ctx->knn_lag : (const u64*)((const char*)ctx->pinned + 3072);   // slots SC_NFAILQ .. SC_BADHINT
             const int64_t fb = (int64_t)(u32)v[0];
@@ -929,7 +929,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             HIPCHK(hipGetLastError());
             // (SC_NFAILQ is written by the list-mode launch itself)
         }
-        if (lagged && !ext) {
+        if (lagged && !ext && !ctx->capturing) {
             if (!ctx->olev_ev) HIPCHK(hipEventCreateWithFlags(&ctx->olev_ev, hipEventDisableTiming));
             HIPCHK(hipMemcpyAsync((char*)ctx->pinned + 3072, ctx->scal.as<u64>() + SC_NFAILQ, 10 * sizeof(u64), hipMemcpyDeviceToHost,
                                   ctx->stream));

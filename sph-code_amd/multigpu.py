@@ -1507,7 +1507,7 @@ def bench_main(args, rank, local_rank, world):
                                         "traffic_source": "not collected for N > 1: the PMC passes run on the single-GPU bench (profiles/r02_final_pmc_per_launch.json)",
                                         "algorithmic_bytes_per_launch": 192.0 * q,
                                         "kernel_ms": ms, "queries_per_launch": q})(
-                kst["ms_search"] / max(kst["steps"], 1), sim.n_owned) if kst["steps"] else None,
+                kst["ms_search"] / max(kst["search_steps"], 1), sim.n_owned) if kst["search_steps"] else None,
             "halo": {"ghosts_per_step_all_ranks": float(cnt[1]), "bytes_sent_per_step_all_ranks": float(cnt[2]),
                      "search_redos": float(cnt[3]),
                      "replans_per_step_rank0": sim.stats.get("replans", 0) / max(args.steps, 1),

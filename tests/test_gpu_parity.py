@@ -1129,3 +1129,37 @@ def test_search_with_outlier_levels_is_exact_on_a_heavy_tailed_cloud(levels, dis
         assert (st["outlier_levels"] > 0) == (levels != "0" and it >= 1), (it, st)     # (step 0 has no hints: plain search)
         pts = d["points"]
         assert np.isfinite(pts).all()
+
+
+@pytest.mark.parametrize("kw", [{}, dict(forms="loop")])
+def test_step_graphs_replay_the_same_trajectory(kw, monkeypatch):
+    """Steps can be replayed as hipGraphs (opt-in, SPHX_GRAPH=1; sphx_step: one real step sizes the grid and takes the
+    search's decisions, the next two are captured with those frozen - one per parity of the double-buffered state - and
+    replayed for up to SPHX_GRAPH_EPOCH steps).  The grid box only steers performance, so a run with graphs (short epochs
+    here: several real steps and re-captures in between) and a run without must agree BIT FOR BIT, step by step and over
+    many steps in one call, in both step modes; and the replays must really have happened.  (Off by default: measured
+    SLOWER than the stream at 1e4 particles - 0.183 -> 0.234 ms per step in loop-form mode: the step there is bound by its
+    ~25 dependent kernels' own latency, not by the host's launch calls)"""
+    import sph_code_amd.ics as ics
+    from sph_code_amd.sim import Simulation
+    n, K = 20000, 40
+    s0 = ics.polytrope_sphere(n)
+    kw = dict(kw)
+    if kw.get("forms") == "loop":
+        kw["d"] = ics.loop_d(s0, K)
+    res = {}
+    for name, env in (("graphs", {"SPHX_GRAPH": "1", "SPHX_GRAPH_EPOCH": "5"}), ("plain", {"SPHX_GRAPH": "0"})):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        sim = Simulation(s0, n_neigh=K, **kw)
+        for _ in range(6):
+            sim.step(1)
+        sim.step(17)
+        res[name] = (sim.download(), sim.stats())
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert res["plain"][1]["graph_steps"] == 0
+    assert res["graphs"][1]["graph_steps"] >= 12 and res["graphs"][1]["steps"] == 23, res["graphs"][1]
+    for key in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities", "num_densities", "pressure", "visc_heat"):
+        assert np.array_equal(res["graphs"][0][key], res["plain"][0][key], equal_nan=True), key
+    assert res["graphs"][0]["dt"] == res["plain"][0]["dt"]
