@@ -1343,7 +1343,11 @@ def bench_main(args, rank, local_rank, world):
     dev = torch.device("cuda", dev_index)
     if world == 1:                               # (SPHX_FORCE_DIST=1 without a launcher: a rendezvous with itself)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29519")
+        if "MASTER_PORT" not in os.environ:          # (a free one: a fixed port may still be held by an earlier run)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
     # an explicit timeout on every collective / p2p wait: a rank that hangs (a peer died, a link did not come up) fails
     # with the phase it was in instead of holding the node until the launcher's own limit
     import datetime
