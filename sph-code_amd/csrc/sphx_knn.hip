@@ -163,8 +163,11 @@ __device__ __forceinline__ void block27_count(const GridParams& g, const int* ce
 #ifndef KNN_LIST_WAVES
 #define KNN_LIST_WAVES 4     // list / outlier-level variants: fewer, fatter waves (the prefetched batch needs registers)
 #endif
+#ifndef KNN_OUTL_WAVES
+#define KNN_OUTL_WAVES 3     // the variants that also walk the outlier levels: 168 VGPRs instead of 128 + 130..170 B of scratch (search -1..2 % on the cube and the blast)
+#endif
 template <int ABL, int LEAN = 0, int LIST = 0, int OUTL = 0>
-__global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
+__global__ __launch_bounds__(KNN_BLOCK, OUTL ? KNN_OUTL_WAVES : LIST ? KNN_LIST_WAVES : KNN_MIN_WAVES) void knn_kernel(KnnArgs a) {
     extern __shared__ int tile_dyn[];                 // [K][KNN_PPB + 1] result tile (sized at launch)
 #define tile(kk, li) tile_dyn[(kk) * (KNN_PPB + 1) + (li)]
     __shared__ u64 stg_key[KNN_BLOCK / 64][128];
@@ -405,10 +408,8 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
             // 10 ms, the whole launch (Sedov blast under hydro_update's sums, from the step its first particle escaped).  Its
             // range geometry is done in fp64 instead (list / level variants only; wave-uniform; padded by 1e-9 relative).
             const bool farq = (LIST || OUTL) && (fabsf(fx) > 3e4f || fabsf(fy) > 3e4f || fabsf(fz) > 3e4f || Rc > 3e4f);
-            const double qxd = (xi - ox) * icell, qyd = (yi - oy) * icell, qzd = (zi - oz) * icell;
-            const double qycd = finite ? qyd : fmin(fmax(qyd, 0.0), (double)ny1 + 1.0), qzcd = finite ? qzd : fmin(fmax(qzd, 0.0), (double)nz1 + 1.0);
-            double Rc2d = (Rcur * icell) * (1.0 + 1e-9) + 1e-6;
-            Rc2d *= Rc2d;
+            // (its fp64 quantities are recomputed per batch of rows from what is live anyway - held across the candidate
+            //  loop they cost every query of the list-mode launch 40 B of scratch per lane: list mode +10..20 %)
 
             for (int rb = 0; rb < (ABL == 3 ? 0 : nrows); rb += 64) {
 #ifdef SPHX_KNN_PROF
@@ -418,6 +419,9 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                 // ---- one lane per (cy,cz) row of cells: clip the row to the search SPHERE ----
                 const int r = rb + lane;
                 int s_row = 0, cnt = 0;
+                // (read with every lane active: the shuffle below sits outside the divergent row set-up)
+                u64 kth_far = KNN_INF;
+                if ((LIST || OUTL) && farq && have_best) kth_far = __shfl(bk, KT - 1, 64);
                 if (r < nrows) {
                     // r / ysp: fp32 estimate (r < 2^24 rows, quotient <= 4096: off by one at most) + fix-up
                     int rz = (int)(((float)r + 0.5f) * inv_ysp);       // (outer index, inner index) = (rz, ry) ...
@@ -443,6 +447,17 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                         // against the query clamped into the grid.  An interior row holds particles whose y and z truly lie in
                         // it, so the true - far - query applies: with the clamped one a query off in two or three axes (a corner
                         // of the clamp cube) kept every row's whole chord however close its K-th best already was.
+                        double icd = icell;
+                        asm volatile("" : "+v"(icd));          // keep this block's values out of the loop's preheader
+                        const double qxd = (xi - ox) * icd, qyd = (yi - oy) * icd, qzd = (zi - oz) * icd;
+                        const double qycd = finite ? qyd : fmin(fmax(qyd, 0.0), (double)ny1 + 1.0),
+                                     qzcd = finite ? qzd : fmin(fmax(qzd, 0.0), (double)nz1 + 1.0);
+                        double Rc2d = (Rcur * icd) * (1.0 + 1e-9) + 1e-6;
+                        Rc2d *= Rc2d;
+                        if (kth_far != KNN_INF) {               // the running K-th best (it only ever shrinks)
+                            const double rp = sqrt(__longlong_as_double((long long)kth_far)) * icd * (1.0 + 1e-9) + 1e-6;
+                            Rc2d = fmin(Rc2d, rp * rp);
+                        }
                         const double qye = (cy == 0 || cy == (int)ny1) ? qycd : qyd, qze = (cz == 0 || cz == (int)nz1) ? qzcd : qzd;
                         const double dyd = fmax(fmax((double)cy - qye, qye - ((double)cy + 1.0)) - 1e-6, 0.0);
                         const double dzd = fmax(fmax((double)cz - qze, qze - ((double)cz + 1.0)) - 1e-6, 0.0);
@@ -598,10 +613,6 @@ __global__ __launch_bounds__(KNN_BLOCK, (LIST || OUTL) ? KNN_LIST_WAVES : KNN_MI
                                 const double rkd = sqrt(__longlong_as_double((long long)kth)) * icell;
                                 const float rk = (float)rkd * 1.00001f + 2e-3f;
                                 Rc2 = fminf(Rc2, rk * rk);
-                                if ((LIST || OUTL) && farq) {
-                                    const double rp = rkd * (1.0 + 1e-9) + 1e-6;
-                                    Rc2d = fmin(Rc2d, rp * rp);
-                                }
                             }
 #ifdef SPHX_KNN_PROF
                             d_iter += (u64)(clock64() - td0);
