@@ -120,6 +120,13 @@ struct KgShared {
 #ifndef KG_MINWAVES
 #define KG_MINWAVES 5
 #endif
+#ifndef KG_MFMA
+#define KG_MFMA 1                    // phase A on the matrix cores where its error bound allows
+#endif
+#define KG_MFMA_PAD 2.0e-3           // acceptance pad of the matrix-core form: D = d^2 - R^2 (1 + pad) < 0
+#define KG_MFMA_KAPPA 6.0e-5         // its error bound: kappa E^2 (cell units)
+#define KG_MFMA_ERRMAX 1.75e-3       // ... which must not exceed this share of the smallest R^2 of the group
+#define KG_MFMA_EMAX 40.0            // and the tile's half extent this many cells (fp16 range: |c|^2 <= 4800, pads at 75)
 __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArgs a) {
     __shared__ f32x4 tile_xy[KG_TCAP / 2];
     __shared__ TileZI tile_zi[KG_TCAP / 2];
@@ -161,10 +168,8 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     bool fail = is_query && !ok;
     // one wide radius among 64 (a rim particle among surface particles) would size the tile for all of them and push the
     // whole group over its caps: a query KG_RSPREAD times above the group's smallest radius goes to the general kernel alone
-    {
-        const double Rmin = wmin(ok ? R : (double)INFINITY);
-        if (ok && R > KG_RSPREAD * Rmin) { ok = false; fail = true; }
-    }
+    const double Rmin = wmin(ok ? R : (double)INFINITY);
+    if (ok && R > KG_RSPREAD * Rmin) { ok = false; fail = true; }
     int why = fail ? 1 : 0;                     // diagnostics: 1 no hint, 2 tile, 3 tolerance, 4 > 64 inside, 5 < K inside, 6 near tie
     const u64 okmask = __builtin_amdgcn_ballot_w64(ok);
     if (wave == 0) {
@@ -205,6 +210,10 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     KG_STAMP(0)
     bool group_ok = sh.ok != 0;
     const double Ox = sh.Ox, Oy = sh.Oy, Oz = sh.Oz;
+    // Phase A on the matrix cores (below) when its error bound KG_MFMA_KAPPA E^2 fits the acceptance pad of every query
+    // of the group (R_i >= Rmin) and the tile's numbers fit fp16's range; else the packed-fp32 form
+    const double Rcmin = Rmin * g.inv_cell;
+    const bool use_mfma = KG_MFMA && sh.E <= KG_MFMA_EMAX && KG_MFMA_KAPPA * sh.E * sh.E <= KG_MFMA_ERRMAX * Rcmin * Rcmin;
     int T = 0;
     if (group_ok) {
         // ---- the rows of cells, 512 at a time (two per thread): the chord of cells that can hold a particle within Rcov
@@ -318,7 +327,9 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             const int nwp = (T + 31) >> 5;
             if (tid < nwp * 32 - T) {
                 const int o = KG_OFF(T + tid);
-                txy[o] = 1e30f; txy[o + 2] = 1e30f; tzi[o] = 1e30f;
+                // (matrix-core form: finite in fp16, |c|^2 = 16875 < 65504, and >= 35 cells from every query on each axis)
+                const float padv = use_mfma ? 75.0f : 1e30f;
+                txy[o] = padv; txy[o + 2] = padv; tzi[o] = padv;
                 reinterpret_cast<int*>(tzi)[o + 2] = -1;
             }
         }
@@ -341,7 +352,92 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     const double tol_rel = ok ? 5.9604644775390625e-08 * (6.93 * sh.E / Rc + 7.5) : 0.0;
     if (ok && !(tol_rel <= 0.5e-4)) { ok = false; fail = true; why = 3; }
     const float r2f = ok ? (float)(Rc * Rc * 1.0002) : -1.0f;
-    {
+    if (use_mfma) {
+        // ---- phase A on the matrix cores.  d^2 - R^2 = |c|^2 - 2 c.q + |q|^2 - R^2 is a 16-deep inner product of a row
+        // made from the candidate and a column made from the query, every fp32 number carried as an fp16 pair hi + lo
+        // (hi = RTZ16(x), lo = RTZ16(x - hi): 20 bits):
+        //   k:          0..2       3    4..6      7   |  8..10      11   12    13   14   15
+        //   candidate:  c_hi       0    c_lo      0   |  c_hi       0    C2hi  C2lo 1    1        (C2 = |c|^2)
+        //   query:     -2 q_hi     0   -2 q_hi    0   | -2 q_lo     0    1     1    Qhi  Qlo      (Q = |q|^2 - R^2 (1 + pad))
+        // One v_mfma_f32_32x32x16_f16 = 32 candidates x 32 queries: lane l holds the column of query l & 31 and the rows
+        // (candidates)  4 (l >> 5) + 8 (r >> 2) + (r & 3)  in its 16 accumulator registers r, so 16 funnel shifts per
+        // lane turn a block's signs into mask bits - 6.4 cycles per candidate and 64 queries where the packed-fp32 form
+        // (3 v_pk_add + 3 v_pk_fma per pair + 1 v_alignbit per candidate, all 4-cycle issues) takes 16.8.
+        // Error: |D - (d^2 - R^2 (1 + pad))| <= KG_MFMA_KAPPA E^2 for coordinates |.| <= E - dropped c_lo q_lo
+        // and the two splits' remainders 18 x 2^-20 E^2, the splits of C2 and Q 7 x 2^-20 E^2, thirteen fp32 additions of
+        // terms summing to <= 13 E^2 in absolute value at 2^-23 each 2.0e-5 E^2: 4.4e-5, 6e-5 taken.  With pad = 2e-3 and
+        // kappa E^2 <= 1.75e-3 Rc^2: every candidate within R_i (as fp32 sees it: + tol_rel <= 0.5e-4) is listed, and an
+        // unlisted one lies beyond R_i^2 x 1.0002 - what the certification below assumes of the packed-fp32 form as well.
+        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float lo, float hi) -> u32 { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(lo, hi)); };
+        auto f_lo = [](u32 d) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d & 0xFFFFu)); };
+        auto f_hi = [](u32 d) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d >> 16)); };
+        const int n32 = lane & 31, hh = lane >> 5;
+        f16x8 Bq[2];
+#pragma unroll
+        for (int H = 0; H < 2; ++H) {
+            const int srcl = 32 * H + n32;
+            const float sx = __shfl(fqx, srcl, 64), sy = __shfl(fqy, srcl, 64), sz = __shfl(fqz, srcl, 64);
+            const float sr = __shfl(ok ? (float)(Rc * Rc * (1.0 + KG_MFMA_PAD)) : -1.0f, srcl, 64);
+            const u32 h01 = pk(sx, sy), h2_ = pk(sz, 0.0f);
+            u32 w0, w1, w2, w3;
+            if (hh == 0) {
+                w0 = pk(-2.0f * f_lo(h01), -2.0f * f_hi(h01)); w1 = pk(-2.0f * f_lo(h2_), 0.0f);
+                w2 = w0; w3 = w1;
+            } else {
+                const float lx = sx - f_lo(h01), ly = sy - f_hi(h01), lz = sz - f_lo(h2_);
+                const u32 l01 = pk(lx, ly), l2_ = pk(lz, 0.0f);
+                w0 = pk(-2.0f * f_lo(l01), -2.0f * f_hi(l01)); w1 = pk(-2.0f * f_lo(l2_), 0.0f);
+                w2 = 0x3C003C00u;                                               // (1, 1)
+                float Q = fmaf(sz, sz, fmaf(sy, sy, sx * sx)) - sr;
+                if (!(sr > 0.0f)) Q = 60000.0f;                                 // no usable query in this column: never negative
+                const u32 qh = pk(Q, 0.0f);
+                w3 = pk(Q, Q - f_lo(qh));
+            }
+            Bq[H] = __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
+        }
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int w = wave; w < nw; w += 4) {
+            const int o = KG_OFF(w * 32 + n32);
+            const float cx = txy[o], cy = txy[o + 2], cz = tzi[o];
+            const u32 h01 = pk(cx, cy), h2_ = pk(cz, 0.0f);
+            u32 w2, w3;
+            if (hh == 0) {
+                w2 = pk(cx - f_lo(h01), cy - f_hi(h01)); w3 = pk(cz - f_lo(h2_), 0.0f);
+            } else {
+                const float C2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+                const u32 ch = pk(C2, 0.0f);
+                w2 = pk(C2, C2 - f_lo(ch)); w3 = 0x3C003C00u;
+            }
+            const f16x8 Ac = __builtin_bit_cast(f16x8, make_uint4(h01, h2_, w2, w3));
+            const f32x16 D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[0], zero16, 0, 0, 0);
+            const f32x16 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[1], zero16, 0, 0, 0);
+            u32 m = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = shift_in_sign(m, D0[r]);         // query n32:      register r -> bit 31 - r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = shift_in_sign(m, D1[r]);         // query 32 + n32: register r -> bit 15 - r
+            if (__builtin_amdgcn_ballot_w64(m != 0u)) {
+                int s0 = 0, s1 = 0;
+                if (m >> 16) s0 = atomicAdd(&cntq[n32], __popc(m >> 16));
+                if (m & 0xFFFFu) s1 = atomicAdd(&cntq[32 + n32], __popc(m & 0xFFFFu));
+                while (__builtin_amdgcn_ballot_w64(m != 0u)) {
+                    if (m != 0u) {
+                        const int j = __clz((int)m);
+                        m &= ~(0x80000000u >> j);
+                        const int r = j & 15;
+                        const int slot_t = w * 32 + 4 * hh + 8 * (r >> 2) + (r & 3);
+                        const bool first = j < 16;
+                        const int pos = first ? s0 : s1;
+                        if (pos < 64) slist[pos * 64 + (first ? n32 : 32 + n32)] = (unsigned short)slot_t;
+                        if (first) ++s0; else ++s1;
+                    }
+                }
+            }
+        }
+    } else {
         const f32x2 qx2 = {fqx, fqx}, qy2 = {fqy, fqy}, qz2 = {fqz, fqz};
         const f32x2 nr2 = {-r2f, -r2f};            // (+1 for lanes without a usable query: never negative)
         for (int w = wave; w < nw; w += 4) {
