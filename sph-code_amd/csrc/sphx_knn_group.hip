@@ -399,8 +399,13 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             Bq[H] = __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
         }
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // MFMA row `n32` carries the candidate of tile slot 32 w + pi(n32), pi chosen so that - after the two halves of the
+        // wave have swapped what they hold of each other's query (v_permlane32_swap: lane l then owns query l, like
+        // everywhere else in this kernel) - bit j of a lane's word (from the top) is tile slot 32 w + j:
+        //   rows 8 a + b (b < 4, accumulator registers of lanes 0..31)  -> slots 4 a + b,  rows 8 a + 4 + b -> 16 + 4 a + b
+        const int pi32 = ((n32 & 4) << 2) | ((n32 >> 3) << 2) | (n32 & 3);
         for (int w = wave; w < nw; w += 4) {
-            const int o = KG_OFF(w * 32 + n32);
+            const int o = KG_OFF(w * 32 + pi32);
             const float cx = txy[o], cy = txy[o + 2], cz = tzi[o];
             const u32 h01 = pk(cx, cy), h2_ = pk(cz, 0.0f);
             u32 w2, w3;
@@ -414,25 +419,24 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             const f16x8 Ac = __builtin_bit_cast(f16x8, make_uint4(h01, h2_, w2, w3));
             const f32x16 D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[0], zero16, 0, 0, 0);
             const f32x16 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[1], zero16, 0, 0, 0);
-            u32 m = 0;
+            u32 m0 = 0, m1 = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = shift_in_sign(m, D0[r]);         // query n32:      register r -> bit 31 - r
+            for (int r = 0; r < 16; ++r) m0 = shift_in_sign(m0, D0[r]);       // query n32:      register r -> bit 15 - r
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = shift_in_sign(m, D1[r]);         // query 32 + n32: register r -> bit 15 - r
+            for (int r = 0; r < 16; ++r) m1 = shift_in_sign(m1, D1[r]);       // query 32 + n32
+            // lanes 0..31 keep m0 and get the upper lanes' m0 (the other 16 rows of query n32); lanes 32..63 get the lower
+            // lanes' m1 and keep their own
+            const auto sw = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+            u32 m = (sw[0] << 16) | sw[1];
             if (__builtin_amdgcn_ballot_w64(m != 0u)) {
-                int s0 = 0, s1 = 0;
-                if (m >> 16) s0 = atomicAdd(&cntq[n32], __popc(m >> 16));
-                if (m & 0xFFFFu) s1 = atomicAdd(&cntq[32 + n32], __popc(m & 0xFFFFu));
+                int slot = 0;
+                if (m != 0u) slot = atomicAdd(&cntq[lane], __popc(m));
                 while (__builtin_amdgcn_ballot_w64(m != 0u)) {
                     if (m != 0u) {
                         const int j = __clz((int)m);
                         m &= ~(0x80000000u >> j);
-                        const int r = j & 15;
-                        const int slot_t = w * 32 + 4 * hh + 8 * (r >> 2) + (r & 3);
-                        const bool first = j < 16;
-                        const int pos = first ? s0 : s1;
-                        if (pos < 64) slist[pos * 64 + (first ? n32 : 32 + n32)] = (unsigned short)slot_t;
-                        if (first) ++s0; else ++s1;
+                        if (slot < 64) slist[slot * 64 + lane] = (unsigned short)(w * 32 + j);
+                        ++slot;
                     }
                 }
             }
