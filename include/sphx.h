@@ -101,6 +101,13 @@ int         sphx_version(void);
  * carries both, so that it can be shown to be the configuration the parity tests ran.                           */
 const char* sphx_build_info(void);
 const char* sphx_tunables(const sphx_ctx* ctx);
+/* Hardware self-test of the search's matrix-core cull (sphx_knn_group.hip, phase A): `blocks` random 32 x 32 blocks of
+ * candidates and queries with coordinates in [-E, E] (cell units, E <= 40) through v_mfma_f32_32x32x16_f16 exactly as the
+ * search forms them, compared with fp64.  max_err_over_E2: the largest |D - (d^2 - R^2 (1 + pad))| / E^2 met; kappa: the
+ * bound the search's certification assumes; wrong_signs: entries beyond that bound whose sign differed (must be 0).
+ * Test infrastructure (tests/test_gpu_parity.py); replaces nothing in the reference. */
+int sphx_selftest_mfma_cull(sphx_ctx* ctx, double E, int blocks, unsigned seed, double* max_err_over_E2,
+                            double* wrong_signs, double* kappa);
 /* Page-locked host memory for the big arrays the array entry points hand back ((N,K) int64 + float64 from
  * sphx_neighbors: 640 MB at N = 1e6, K = 40): device-to-host copies into it run at the link's rate instead of
  * being staged through the runtime's bounce buffers (~4x).  Any host pointer is accepted everywhere; this is

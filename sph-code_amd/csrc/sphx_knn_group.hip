@@ -127,6 +127,45 @@ struct KgShared {
 #define KG_MFMA_KAPPA 6.0e-5         // its error bound: kappa E^2 (cell units)
 #define KG_MFMA_ERRMAX 1.75e-3       // ... which must not exceed this share of the smallest R^2 of the group
 #define KG_MFMA_EMAX 40.0            // and the tile's half extent this many cells (fp16 range: |c|^2 <= 4800, pads at 75)
+
+// ---- operands of the matrix-core form of phase A (see the kernel; also driven by sphx_selftest_mfma_cull) ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ u32 kg_pk(float lo, float hi) { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ float kg_flo(u32 d) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d & 0xFFFFu)); }
+__device__ __forceinline__ float kg_fhi(u32 d) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d >> 16)); }
+// row of candidate (cx, cy, cz): k 0..7 in the lanes of half 0, k 8..15 in those of half 1
+__device__ __forceinline__ f16x8 kg_cand_frag(float cx, float cy, float cz, int hh) {
+    const u32 h01 = kg_pk(cx, cy), h2_ = kg_pk(cz, 0.0f);
+    u32 w2, w3;
+    if (hh == 0) {
+        w2 = kg_pk(cx - kg_flo(h01), cy - kg_fhi(h01)); w3 = kg_pk(cz - kg_flo(h2_), 0.0f);
+    } else {
+        const float C2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+        const u32 ch = kg_pk(C2, 0.0f);
+        w2 = kg_pk(C2, C2 - kg_flo(ch)); w3 = 0x3C003C00u;                     // (1, 1)
+    }
+    return __builtin_bit_cast(f16x8, make_uint4(h01, h2_, w2, w3));
+}
+// column of query (sx, sy, sz) with padded squared radius sr (sr <= 0: no usable query - the column never accepts)
+__device__ __forceinline__ f16x8 kg_query_frag(float sx, float sy, float sz, float sr, int hh) {
+    const u32 h01 = kg_pk(sx, sy), h2_ = kg_pk(sz, 0.0f);
+    u32 w0, w1, w2, w3;
+    if (hh == 0) {
+        w0 = kg_pk(-2.0f * kg_flo(h01), -2.0f * kg_fhi(h01)); w1 = kg_pk(-2.0f * kg_flo(h2_), 0.0f);
+        w2 = w0; w3 = w1;
+    } else {
+        const float lx = sx - kg_flo(h01), ly = sy - kg_fhi(h01), lz = sz - kg_flo(h2_);
+        const u32 l01 = kg_pk(lx, ly), l2_ = kg_pk(lz, 0.0f);
+        w0 = kg_pk(-2.0f * kg_flo(l01), -2.0f * kg_fhi(l01)); w1 = kg_pk(-2.0f * kg_flo(l2_), 0.0f);
+        w2 = 0x3C003C00u;
+        float Q = fmaf(sz, sz, fmaf(sy, sy, sx * sx)) - sr;
+        if (!(sr > 0.0f)) Q = 60000.0f;
+        const u32 qh = kg_pk(Q, 0.0f);
+        w3 = kg_pk(Q, Q - kg_flo(qh));
+    }
+    return __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
+}
 __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArgs a) {
     __shared__ f32x4 tile_xy[KG_TCAP / 2];
     __shared__ TileZI tile_zi[KG_TCAP / 2];
@@ -368,12 +407,6 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         // terms summing to <= 13 E^2 in absolute value at 2^-23 each 2.0e-5 E^2: 4.4e-5, 6e-5 taken.  With pad = 2e-3 and
         // kappa E^2 <= 1.75e-3 Rc^2: every candidate within R_i (as fp32 sees it: + tol_rel <= 0.5e-4) is listed, and an
         // unlisted one lies beyond R_i^2 x 1.0002 - what the certification below assumes of the packed-fp32 form as well.
-        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-        typedef float f32x16 __attribute__((ext_vector_type(16)));
-        typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-        auto pk = [](float lo, float hi) -> u32 { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(lo, hi)); };
-        auto f_lo = [](u32 d) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d & 0xFFFFu)); };
-        auto f_hi = [](u32 d) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(d >> 16)); };
         const int n32 = lane & 31, hh = lane >> 5;
         f16x8 Bq[2];
 #pragma unroll
@@ -381,22 +414,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             const int srcl = 32 * H + n32;
             const float sx = __shfl(fqx, srcl, 64), sy = __shfl(fqy, srcl, 64), sz = __shfl(fqz, srcl, 64);
             const float sr = __shfl(ok ? (float)(Rc * Rc * (1.0 + KG_MFMA_PAD)) : -1.0f, srcl, 64);
-            const u32 h01 = pk(sx, sy), h2_ = pk(sz, 0.0f);
-            u32 w0, w1, w2, w3;
-            if (hh == 0) {
-                w0 = pk(-2.0f * f_lo(h01), -2.0f * f_hi(h01)); w1 = pk(-2.0f * f_lo(h2_), 0.0f);
-                w2 = w0; w3 = w1;
-            } else {
-                const float lx = sx - f_lo(h01), ly = sy - f_hi(h01), lz = sz - f_lo(h2_);
-                const u32 l01 = pk(lx, ly), l2_ = pk(lz, 0.0f);
-                w0 = pk(-2.0f * f_lo(l01), -2.0f * f_hi(l01)); w1 = pk(-2.0f * f_lo(l2_), 0.0f);
-                w2 = 0x3C003C00u;                                               // (1, 1)
-                float Q = fmaf(sz, sz, fmaf(sy, sy, sx * sx)) - sr;
-                if (!(sr > 0.0f)) Q = 60000.0f;                                 // no usable query in this column: never negative
-                const u32 qh = pk(Q, 0.0f);
-                w3 = pk(Q, Q - f_lo(qh));
-            }
-            Bq[H] = __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
+            Bq[H] = kg_query_frag(sx, sy, sz, sr, hh);
         }
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // MFMA row `n32` carries the candidate of tile slot 32 w + pi(n32), pi chosen so that - after the two halves of the
@@ -407,16 +425,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         for (int w = wave; w < nw; w += 4) {
             const int o = KG_OFF(w * 32 + pi32);
             const float cx = txy[o], cy = txy[o + 2], cz = tzi[o];
-            const u32 h01 = pk(cx, cy), h2_ = pk(cz, 0.0f);
-            u32 w2, w3;
-            if (hh == 0) {
-                w2 = pk(cx - f_lo(h01), cy - f_hi(h01)); w3 = pk(cz - f_lo(h2_), 0.0f);
-            } else {
-                const float C2 = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
-                const u32 ch = pk(C2, 0.0f);
-                w2 = pk(C2, C2 - f_lo(ch)); w3 = 0x3C003C00u;
-            }
-            const f16x8 Ac = __builtin_bit_cast(f16x8, make_uint4(h01, h2_, w2, w3));
+            const f16x8 Ac = kg_cand_frag(cx, cy, cz, hh);
             const f32x16 D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[0], zero16, 0, 0, 0);
             const f32x16 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[1], zero16, 0, 0, 0);
             u32 m0 = 0, m1 = 0;
@@ -723,5 +732,62 @@ int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a0) {
         fprintf(stderr, "[sphx] grouped search cycles/group (thread 0): setup %.0f rows %.0f stage %.0f phaseA %.0f phaseB %.0f sort+certify %.0f output %.0f tail %.0f\n",
                 h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
     }
+    return SPHX_OK;
+}
+
+// ---- self-test of the matrix-core form's error bound on the hardware it runs on (tests/test_gpu_parity.py) ----
+// One wave per block; every block draws 32 candidates and 32 queries with coordinates uniform in [-E, E] and radii in
+// [0.2 E, E], forms D as phase A does and compares all 1024 entries with d^2 - R^2 (1 + pad) in fp64 from the same fp32
+// inputs.  out[0] = max |D - exact| / E^2 (the bound is KG_MFMA_KAPPA), out[1] = entries whose sign differs although
+// |exact| > KG_MFMA_KAPPA E^2 (must be 0).
+__global__ __launch_bounds__(64) void kg_selftest_kernel(float E, unsigned seed, double* out) {
+    __shared__ float cx[32], cy[32], cz[32], qx[32], qy[32], qz[32], qr[32];
+    const int lane = threadIdx.x, n32 = lane & 31, hh = lane >> 5;
+    unsigned st = seed * 2654435761u + (blockIdx.x * 64u + lane) * 40503u + 12345u;
+    auto rnd = [&]() -> float { st = st * 1664525u + 1013904223u; return (float)(st >> 8) * (1.0f / 16777216.0f); };
+    if (hh == 0) { cx[n32] = (2.f * rnd() - 1.f) * E; cy[n32] = (2.f * rnd() - 1.f) * E; cz[n32] = (2.f * rnd() - 1.f) * E; }
+    else {
+        qx[n32] = (2.f * rnd() - 1.f) * E; qy[n32] = (2.f * rnd() - 1.f) * E; qz[n32] = (2.f * rnd() - 1.f) * E;
+        const float R = (0.2f + 0.8f * rnd()) * E;
+        qr[n32] = (float)((double)R * (double)R * (1.0 + KG_MFMA_PAD));
+    }
+    __syncthreads();
+    const f16x8 A = kg_cand_frag(cx[n32], cy[n32], cz[n32], hh);
+    const f16x8 B = kg_query_frag(qx[n32], qy[n32], qz[n32], qr[n32], hh);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero16, 0, 0, 0);
+    double worst = 0.0, wrong = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 4 * hh + 8 * (r >> 2) + (r & 3);
+        const double dx = (double)cx[row] - (double)qx[n32], dy = (double)cy[row] - (double)qy[n32], dz = (double)cz[row] - (double)qz[n32];
+        const double exact = dx * dx + dy * dy + dz * dz - (double)qr[n32];
+        const double err = fabs((double)D[r] - exact) / ((double)E * (double)E);
+        worst = fmax(worst, err);
+        if (fabs(exact) > KG_MFMA_KAPPA * (double)E * (double)E && ((D[r] < 0.0f) != (exact < 0.0))) wrong += 1.0;
+    }
+    worst = wmax(worst);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wrong += __shfl_xor(wrong, o, 64);
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned long long*>(&out[0]), (unsigned long long)__double_as_longlong(worst));
+        atomicAdd(&out[1], wrong);
+    }
+}
+extern "C" int sphx_selftest_mfma_cull(sphx_ctx* ctx, double E, int blocks, unsigned seed, double* max_err_over_E2,
+                                       double* wrong_signs, double* kappa) {
+    if (!ctx || !max_err_over_E2 || !wrong_signs || blocks < 1 || !(E > 0.0) || E > KG_MFMA_EMAX)
+        return sphx_set_err(ctx, SPHX_E_ARG, "sphx_selftest_mfma_cull: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    SPHX_TRY(sphx_ensure(ctx, ctx->scal_tmp, 4096));
+    double* out = ctx->scal_tmp.as<double>();
+    HIPCHK(hipMemsetAsync(out, 0, 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(kg_selftest_kernel, dim3(blocks), dim3(64), 0, ctx->stream, (float)E, seed, out);
+    HIPCHK(hipGetLastError());
+    double h[2];
+    HIPCHK(hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *max_err_over_E2 = h[0]; *wrong_signs = h[1];
+    if (kappa) *kappa = KG_MFMA_KAPPA;
     return SPHX_OK;
 }

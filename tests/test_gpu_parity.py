@@ -1163,3 +1163,21 @@ def test_step_graphs_replay_the_same_trajectory(kw, monkeypatch):
     for key in ("points", "velocities", "total_accel", "E_internal", "T", "sizes", "densities", "num_densities", "pressure", "visc_heat"):
         assert np.array_equal(res["graphs"][0][key], res["plain"][0][key], equal_nan=True), key
     assert res["graphs"][0]["dt"] == res["plain"][0]["dt"]
+
+
+@pytest.mark.parametrize("E", [1.0, 4.0, 12.0, 40.0])
+def test_matrix_core_cull_stays_inside_its_error_bound(E):
+    """Phase A of the grouped search forms d^2 - R^2 (1 + pad) on the matrix cores from fp16 hi/lo splits
+    (sphx_knn_group.hip); the certification of its results (nsc:541-552 replaced exactly) assumes
+    |D - exact| <= kappa E^2 for coordinates within E cells of the tile's centre.  The library forms 4096 random 32 x 32
+    blocks exactly as the search does and compares every entry with fp64: the worst error must stay inside kappa, and no
+    entry further than kappa E^2 from the threshold may land on its wrong side."""
+    import ctypes as C
+    from sph_code_amd import _lib
+    ctx = _lib.Context()
+    worst, wrong, kappa = C.c_double(), C.c_double(), C.c_double()
+    rc = ctx.lib.sphx_selftest_mfma_cull(ctx.h, float(E), 4096, 7, C.byref(worst), C.byref(wrong), C.byref(kappa))
+    assert rc == 0
+    print("E = %g: max |D - exact| / E^2 = %.3g (bound %.3g), wrong signs %g" % (E, worst.value, kappa.value, wrong.value))
+    assert 0.0 < worst.value <= kappa.value
+    assert wrong.value == 0.0
