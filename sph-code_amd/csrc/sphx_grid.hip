@@ -185,7 +185,7 @@ __global__ __launch_bounds__(RED_BLOCK) void grid_count_fused(FusedCountArgs a) 
     double su[3] = {0.0, 0.0, 0.0}, sq[3] = {0.0, 0.0, 0.0}, cnt = 0.0;
     const GridParams g = a.g;
     if (a.ct_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.ct_reset = SPHX_CT_NONE;
-    if (a.zero_int && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_int = 0;
+    if (a.zero_int && blockIdx.x == 0 && threadIdx.x == 0) { a.zero_int[0] = 0; a.zero_int[1] = 0; }   // fail count, tie count
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
         double v[3] = {a.x[i], a.y[i], a.z[i]};
         if (a.vx) {                                            // drv:233-238

@@ -917,7 +917,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             int* flist = ctx->fail_list.as<int>();
             int* fcount = flist + a.npad;
             if (!(ctx->fcount_zeroed == ctx->fail_list.p && ctx->fcount_zeroed_n == n))     // (else: the grid build's first kernel did it)
-                HIPCHK(hipMemsetAsync(fcount, 0, sizeof(int), ctx->stream));
+                HIPCHK(hipMemsetAsync(fcount, 0, 2 * sizeof(int), ctx->stream));           // (fail count, tie count)
             ctx->fcount_zeroed = nullptr;
             KnnGroupArgs ga;
             ga.n = a.n; ga.k = a.k; ga.npad = a.npad; ga.n_active = a.n_active;
@@ -925,7 +925,14 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
             ga.g = a.g; ga.rsearch = a.rsearch; ga.hint_by_id = a.hint_by_id; ga.rscale = a.rscale; ga.rbound = a.rbound;
             ga.nbr = a.nbr; ga.h_sorted = lean ? a.h_sorted : nullptr; ga.h_by_id = lean2 ? a.h_by_id : nullptr;
             ga.fail_list = flist; ga.fail_count = fcount; ga.counters = a.counters;
+            ga.tie_list = nullptr; ga.tie_count = fcount + 1; ga.tie_cap = 0;
+            if (ctx->tie_fix) {
+                ga.tie_cap = a.npad / 16 + 1024;
+                SPHX_TRY(sphx_ensure(ctx, ctx->tie_list, (size_t)ga.tie_cap * sizeof(int4)));
+                ga.tie_list = ctx->tie_list.as<int4>();
+            }
             SPHX_TRY(sphx_knn_group(ctx, ga));
+            if (ga.tie_list) SPHX_TRY(sphx_knn_tie_fix(ctx, ga));
             a.qlist = flist; a.qcount = fcount;
             int lblocks = (int)((ctx->list_len_last / 32 + 255) / 256) * 256;
             lblocks = lblocks < KNN_LIST_BLOCKS ? KNN_LIST_BLOCKS : (lblocks > KNN_LIST_BLOCKS_MAX ? KNN_LIST_BLOCKS_MAX : lblocks);

@@ -629,6 +629,8 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     // rank r of a query now sits in lane part = r / 16, register r % 16
 
     // ---- certify: consecutive keys among the first K+1 further apart than twice the error bound ----
+    u32 res16 = 0;                              // bit u: the near tie of ranks 16 part + u, + 1 goes to knn_tie_fix
+    int tie_base = 0;
     {
         // bins of 2^-21 R^2(1.0002): each d2 within tol of the truth, each key a floor of (d2 x a rounded scale): two keys
         // further apart than 2 tol + 2 bins are in their true order
@@ -638,12 +640,25 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         // the same margin again, or an unlisted particle could be the true K-th (the list is then too short in truth)
         const u32 safe = okq ? (u32)(2097152.0 * (1.0 - 2.0 * tol_q / 1.0002)) - 2u : 0u;
         bool amb = false, edge = false;
+        u32 g16 = 0;                            // bit u: ranks r = 16 part + u and r + 1 (r <= K) are closer than the window
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int r = part * 16 + u;
             const u32 nxt = (u < 15) ? key[(u + 1) & 15] : (part < 3 ? nextfirst : 0xFFFFFFFFu);
-            if (r < K && nxt != 0xFFFFFFFFu && (nxt >> 11) - (key[u] >> 11) <= win) amb = true;
+            if (r <= K && nxt != 0xFFFFFFFFu && (nxt >> 11) - (key[u] >> 11) <= win) g16 |= 1u << u;
             if (r == K - 1 && (key[u] >> 11) > safe) edge = true;
+        }
+        {
+            // A near tie of TWO consecutive ranks with certain neighbours on both sides (ranks r - 1 | r, r + 1 | r + 2 in
+            // certain order) is left to knn_tie_fix, which orders the two by their exact fp64 distances (index breaks
+            // exact ties, as in the general kernel) - half of what this kernel used to hand on.  Chains of
+            // three and pairs that straddle two lanes still fail over.
+            const int nk = K - part * 16;                                    // ranks r < K held by this lane
+            const u32 kmask = nk >= 16 ? 0xFFFFu : (nk <= 0 ? 0u : ((1u << nk) - 1u));
+            const u32 prevG = part > 0 ? (((u32)__builtin_amdgcn_update_dpp(0, (int)g16, 0x90, 0xF, 0xF, false) >> 15) & 1u) : 0u;   // quad_perm [0,0,1,2]: lane - 1
+            const u32 a16 = g16 & kmask;
+            res16 = (a.tie_list && okq) ? (a16 & ~((g16 << 1) | prevG) & ~(g16 >> 1) & 0x7FFFu) : 0u;
+            amb = (a16 & ~res16) != 0u;
         }
         // any of the query's four lanes
         int am = (amb ? 1 : 0) | (edge ? 2 : 0);
@@ -654,6 +669,15 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         if (a.exp_noamb) am &= ~1;
 #endif
         if (okq && (am & 1)) { okq = false; failq = true; q_why = 6; }
+        // room in the tie list is reserved here: a query whose entries do not fit fails over like any other near tie
+        if (__builtin_amdgcn_ballot_w64(okq && res16 != 0u)) {          // (rare: under 1 % of the queries)
+            const int ne = (okq && res16 != 0u) ? __popc(res16) : 0;
+            if (ne) tie_base = atomicAdd(a.tie_count, ne);
+            int ov = (ne && tie_base + ne > a.tie_cap) ? 1 : 0;
+            ov |= __builtin_amdgcn_update_dpp(0, ov, 0xB1, 0xF, 0xF, true);
+            ov |= __builtin_amdgcn_update_dpp(0, ov, 0x4E, 0xF, 0xF, true);
+            if (okq && ov) { okq = false; failq = true; q_why = 6; }
+        }
     }
     KG_STAMP(5)
     // ---- outputs: rank r = 16 part + u ----
@@ -683,6 +707,17 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         if (mine) {
             const double hval = sqrt(dist2_nofma(lx - sx, ly - sy, lz - sz));
             if (a.h_by_id) a.h_by_id[qid_q] = hval; else a.h_sorted[qs_q] = hval;
+        }
+        if (__builtin_amdgcn_ballot_w64(okq && res16 != 0u)) {
+            int base = tie_base;
+            const u32 mine16 = okq ? res16 : 0u;
+#pragma unroll
+            for (int u = 0; u < 15; ++u) {
+                if ((mine16 >> u) & 1u) {
+                    a.tie_list[base] = make_int4(pq, part * 16 + u, tidx[KG_OFF(key[u] & 2047u) + 2], tidx[KG_OFF(key[u + 1] & 2047u) + 2]);
+                    ++base;
+                }
+            }
         }
     }
     KG_STAMP(6)
@@ -732,6 +767,35 @@ int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a0) {
         fprintf(stderr, "[sphx] grouped search cycles/group (thread 0): setup %.0f rows %.0f stage %.0f phaseA %.0f phaseB %.0f sort+certify %.0f output %.0f tail %.0f\n",
                 h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
     }
+    return SPHX_OK;
+}
+
+// ---- near ties left by the grouped kernel: the two ranks ordered by their exact distances --------------------------
+// One thread per entry {query slot p, rank r, candidates a (rank r), b (rank r + 1)}: order = (exact fp64 d^2, storage
+// index) as in knn_kernel (kv_less).  If b comes first the two list entries are exchanged; when rank K - 1 is involved the
+// radius follows (r = K - 1: b was the unlisted (K+1)-th; r = K - 2: the K-th is now a).
+__global__ __launch_bounds__(256) void knn_tie_fix_kernel(KnnGroupArgs a) {
+    const int total = min(*a.tie_count, a.tie_cap);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int4 t = a.tie_list[e];
+        const int p = t.x, r = t.y, ia = t.z, ib = t.w;
+        const int qs = a.qorder ? a.qorder[p] : p;
+        const double qx = a.x[qs], qy = a.y[qs], qz = a.z[qs];
+        const double da = dist2_nofma(a.x[ia] - qx, a.y[ia] - qy, a.z[ia] - qz);
+        const double db = dist2_nofma(a.x[ib] - qx, a.y[ib] - qy, a.z[ib] - qz);
+        if (db < da || (db == da && ib < ia)) {
+            a.nbr[(size_t)r * a.npad + p] = ib;
+            if (r + 1 < a.k) a.nbr[(size_t)(r + 1) * a.npad + p] = ia;
+            if (r >= a.k - 2) {
+                const double hval = sqrt(r == a.k - 1 ? db : da);
+                if (a.h_by_id) a.h_by_id[a.id[qs]] = hval; else a.h_sorted[qs] = hval;
+            }
+        }
+    }
+}
+int sphx_knn_tie_fix(sphx_ctx* ctx, const KnnGroupArgs& a) {
+    hipLaunchKernelGGL(knn_tie_fix_kernel, dim3(64), dim3(256), 0, ctx->stream, a);
+    HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
 
