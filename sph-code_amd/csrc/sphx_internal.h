@@ -223,7 +223,7 @@ struct sphx_ctx {
     bool olev_ev_valid = false;
     u64 farq_seen = 0;              // SC_FARQ as last read (the counter only grows)
     int64_t farq_last = 0;          // far queries met by the previous hinted search
-    DevBuf tie_list;                       // int4 {query slot, rank, index a, index b}: near ties the grouped search leaves to knn_tie_fix
+    DevBuf tie_list;                       // int4 {query slot, rank, index a, index b}: near ties the grouped search leaves to the list-mode launch's tie blocks
     bool tie_fix = true;
     const void* fcount_zeroed = nullptr;   // the fail-list allocation whose counter the grid build has zeroed for this step
     int64_t fcount_zeroed_n = 0;

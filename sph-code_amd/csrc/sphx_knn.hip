@@ -59,6 +59,11 @@ struct KnnArgs {
     const int* qcount;
     OutLevels ol;              // OUTL = 1: the outlier levels of the current grid (ol.L >= 1)
     int distrust;              // hints are upper bounds at best: every radius is seeded from the local cell counts
+    // list mode: the launch's blocks beyond list_blocks order the near ties the grouped search left (sphx_knn_group.hip:
+    // the entries' queries are not on the list) - beside the list's queries instead of in a launch of their own
+    const int4* tie_list;
+    const int* tie_count;
+    int tie_cap, list_blocks;
 };
 
 #include "sphx_wave.h"
@@ -178,6 +183,28 @@ __global__ __launch_bounds__(KNN_BLOCK, OUTL ? KNN_OUTL_WAVES : LIST ? KNN_LIST_
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nblk = (LIST && a.tie_list) ? a.list_blocks : (int)gridDim.x;      // blocks that walk queries
+    if (LIST && a.tie_list && (int)blockIdx.x >= nblk) {
+        // order = (exact fp64 d^2, storage index), kv_less below; entry {query slot p, rank r, candidates a (rank r), b (r + 1)}
+        const int nt = min(*a.tie_count, a.tie_cap);
+        for (int e = ((int)blockIdx.x - nblk) * KNN_BLOCK + (int)threadIdx.x; e < nt; e += ((int)gridDim.x - nblk) * KNN_BLOCK) {
+            const int4 t = a.tie_list[e];
+            const int p = t.x, r = t.y, ia = t.z, ib = t.w;
+            const int qs_ = a.qorder ? a.qorder[p] : p;
+            const double qx_ = a.x[qs_], qy_ = a.y[qs_], qz_ = a.z[qs_];
+            const double da = dist2_nofma(a.x[ia] - qx_, a.y[ia] - qy_, a.z[ia] - qz_);
+            const double db = dist2_nofma(a.x[ib] - qx_, a.y[ib] - qy_, a.z[ib] - qz_);
+            if (db < da || (db == da && ib < ia)) {
+                a.nbr[(size_t)r * a.npad + p] = ib;
+                if (r + 1 < a.k) a.nbr[(size_t)(r + 1) * a.npad + p] = ia;
+                if (r >= a.k - 2) {          // rank K - 1 changed hands: r = K - 1, b was the unlisted (K+1)-th; r = K - 2, the K-th is now a
+                    const double hv = sqrt(r == a.k - 1 ? db : da);
+                    if (LEAN == 2) a.h_by_id[a.id[qs_]] = hv; else a.h_sorted[qs_] = hv;
+                }
+            }
+        }
+        return;
+    }
     const int total = LIST ? *a.qcount : a.n;          // queries: list entries, or all particles
     int vblock = LIST ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x);
     const GridParams g = a.g;
@@ -203,8 +230,8 @@ __global__ __launch_bounds__(KNN_BLOCK, OUTL ? KNN_OUTL_WAVES : LIST ? KNN_LIST_
     // In list mode the list is dealt out wave by wave instead - entry r NW + w goes to wave w of all NW as its r-th -
     // because the list's heavy entries come in runs (the 64 queries of an overflowed group, a pile of escapers in one
     // boundary cell): consecutive entries must not queue up behind each other in one wave.
-    const int list_pass = LIST ? (vblock - (int)blockIdx.x) / (int)gridDim.x : 0;
-    const int NWV = (int)gridDim.x * (KNN_BLOCK / 64);
+    const int list_pass = LIST ? (vblock - (int)blockIdx.x) / nblk : 0;
+    const int NWV = nblk * (KNN_BLOCK / 64);
     auto entry_of = [&](int li) -> int {
         if (!LIST) return base + li;
         const int wv = li / (PPB / 4), turn = li % (PPB / 4);
@@ -767,7 +794,7 @@ __global__ __launch_bounds__(KNN_BLOCK, OUTL ? KNN_OUTL_WAVES : LIST ? KNN_LIST_
             }
         }
     }
-    vblock += gridDim.x;
+    vblock += nblk;
     } while (LIST);
     if (lane == 0 && a.counters) {
         atomicAdd(&a.counters[SC_CAND], ncand);
@@ -809,6 +836,7 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
     a.rsearch = rsearch;
     a.hint_by_id = ctx->knn_hint_by_id ? 1 : 0;
     a.rscale = rscale;
+    a.tie_list = nullptr; a.tie_count = nullptr; a.tie_cap = 0; a.list_blocks = 0;
     a.rbound = (rbound > 0.0) ? rbound : INFINITY;
     a.nbr = out.nbr;
     a.list64 = out.list64;
@@ -932,17 +960,21 @@ int sphx_knn(sphx_ctx* ctx, int64_t n, int k, const double* xs, const double* ys
                 ga.tie_list = ctx->tie_list.as<int4>();
             }
             SPHX_TRY(sphx_knn_group(ctx, ga));
-            if (ga.tie_list) SPHX_TRY(sphx_knn_tie_fix(ctx, ga));
             a.qlist = flist; a.qcount = fcount;
             int lblocks = (int)((ctx->list_len_last / 32 + 255) / 256) * 256;
             lblocks = lblocks < KNN_LIST_BLOCKS ? KNN_LIST_BLOCKS : (lblocks > KNN_LIST_BLOCKS_MAX ? KNN_LIST_BLOCKS_MAX : lblocks);
             if (lblocks > blocks) lblocks = blocks;
+            int tblocks = 0;                      // near ties: ordered by 16 further blocks of the same launch
+            if (ga.tie_list) {
+                a.tie_list = ga.tie_list; a.tie_count = ga.tie_count; a.tie_cap = ga.tie_cap; a.list_blocks = lblocks;
+                tblocks = 16;
+            }
             if (a.ol.L > 0) {
-                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
-                else hipLaunchKernelGGL((knn_kernel<0, 2, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1, 1>), dim3(lblocks + tblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2, 1, 1>), dim3(lblocks + tblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
             } else {
-                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
-                else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                if (lean) hipLaunchKernelGGL((knn_kernel<0, 1, 1>), dim3(lblocks + tblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
+                else hipLaunchKernelGGL((knn_kernel<0, 2, 1>), dim3(lblocks + tblocks), dim3(KNN_BLOCK), tile_bytes, ctx->stream, a);
             }
             HIPCHK(hipGetLastError());
             // (SC_NFAILQ is written by the list-mode launch itself)

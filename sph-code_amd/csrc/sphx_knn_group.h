@@ -27,7 +27,7 @@ struct KnnGroupArgs {
     int* nbr;                  // [k][npad]
     double* h_sorted;          // one of the two
     double* h_by_id;
-    int4* tie_list;            // near ties between two consecutive ranks, left to knn_tie_fix (nullable: such queries fail over)
+    int4* tie_list;            // near ties between two consecutive ranks, left to the list-mode launch's tie blocks (nullable: such queries fail over)
     int* tie_count;
     int tie_cap;
     int* fail_list;            // processing slots this kernel could not certify
@@ -37,4 +37,3 @@ struct KnnGroupArgs {
     u64* prof;                 // diagnostics (nullptr in the product): per-section cycle sums
 };
 int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a);
-int sphx_knn_tie_fix(sphx_ctx* ctx, const KnnGroupArgs& a);

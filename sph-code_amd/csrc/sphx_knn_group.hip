@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     // rank r of a query now sits in lane part = r / 16, register r % 16
 
     // ---- certify: consecutive keys among the first K+1 further apart than twice the error bound ----
-    u32 res16 = 0;                              // bit u: the near tie of ranks 16 part + u, + 1 goes to knn_tie_fix
+    u32 res16 = 0;                              // bit u: the near tie of ranks 16 part + u, + 1 goes to the tie list
     int tie_base = 0;
     {
         // bins of 2^-21 R^2(1.0002): each d2 within tol of the truth, each key a floor of (d2 x a rounded scale): two keys
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         }
         {
             // A near tie of TWO consecutive ranks with certain neighbours on both sides (ranks r - 1 | r, r + 1 | r + 2 in
-            // certain order) is left to knn_tie_fix, which orders the two by their exact fp64 distances (index breaks
+            // certain order) is left to the tie blocks of the list-mode launch (sphx_knn.hip), which order the two by their exact fp64 distances (index breaks
             // exact ties, as in the general kernel) - half of what this kernel used to hand on.  Chains of
             // three and pairs that straddle two lanes still fail over.
             const int nk = K - part * 16;                                    // ranks r < K held by this lane
@@ -767,35 +767,6 @@ int sphx_knn_group(sphx_ctx* ctx, const KnnGroupArgs& a0) {
         fprintf(stderr, "[sphx] grouped search cycles/group (thread 0): setup %.0f rows %.0f stage %.0f phaseA %.0f phaseB %.0f sort+certify %.0f output %.0f tail %.0f\n",
                 h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
     }
-    return SPHX_OK;
-}
-
-// ---- near ties left by the grouped kernel: the two ranks ordered by their exact distances --------------------------
-// One thread per entry {query slot p, rank r, candidates a (rank r), b (rank r + 1)}: order = (exact fp64 d^2, storage
-// index) as in knn_kernel (kv_less).  If b comes first the two list entries are exchanged; when rank K - 1 is involved the
-// radius follows (r = K - 1: b was the unlisted (K+1)-th; r = K - 2: the K-th is now a).
-__global__ __launch_bounds__(256) void knn_tie_fix_kernel(KnnGroupArgs a) {
-    const int total = min(*a.tie_count, a.tie_cap);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int4 t = a.tie_list[e];
-        const int p = t.x, r = t.y, ia = t.z, ib = t.w;
-        const int qs = a.qorder ? a.qorder[p] : p;
-        const double qx = a.x[qs], qy = a.y[qs], qz = a.z[qs];
-        const double da = dist2_nofma(a.x[ia] - qx, a.y[ia] - qy, a.z[ia] - qz);
-        const double db = dist2_nofma(a.x[ib] - qx, a.y[ib] - qy, a.z[ib] - qz);
-        if (db < da || (db == da && ib < ia)) {
-            a.nbr[(size_t)r * a.npad + p] = ib;
-            if (r + 1 < a.k) a.nbr[(size_t)(r + 1) * a.npad + p] = ia;
-            if (r >= a.k - 2) {
-                const double hval = sqrt(r == a.k - 1 ? db : da);
-                if (a.h_by_id) a.h_by_id[a.id[qs]] = hval; else a.h_sorted[qs] = hval;
-            }
-        }
-    }
-}
-int sphx_knn_tie_fix(sphx_ctx* ctx, const KnnGroupArgs& a) {
-    hipLaunchKernelGGL(knn_tie_fix_kernel, dim3(64), dim3(256), 0, ctx->stream, a);
-    HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
 
