@@ -11,8 +11,9 @@
 //      can (box + sphere, the Minkowski sum) - contiguous particle ranges of the cell-sorted arrays;
 //   2. those ~1000 candidates are staged ONCE into an LDS tile as 16-B records {x,y,z relative to the
 //      group's centre in cell units as fp32, particle index}: coalesced loads, full lanes;
-//   3. phase A: every lane runs over the whole tile with broadcast LDS reads (one ds_read_b128 per
-//      candidate per wave) and shifts "inside my radius" into a per-lane bit mask (v_addc: one instruction);
+//   3. phase A: every query against the whole tile - on the MATRIX CORES where the error bound allows (d^2 - R^2 as a
+//      16-deep inner product of fp16 hi/lo splits, v_mfma_f32_32x32x16_f16: 32 candidates x 32 queries per instruction,
+//      the signs shifted into per-lane mask words), else in packed fp32 with broadcast LDS reads;
 //   4. phase B: each lane turns its ~50 set bits into 32-bit keys  (21-bit quantised d^2/R^2) << 11 | tile
 //      slot  held in 64 REGISTERS, and orders them with Batcher's odd-even merge network on registers
 //      (543 compare-exchanges = 1086 v_min/v_max for 64 queries at once: 17 instructions per query);
