@@ -241,16 +241,6 @@ __global__ __launch_bounds__(RED_BLOCK) void grid_count_fused(FusedCountArgs a) 
     }
 }
 
-// exclusive scan of n ints, out[n] = total (in[n] must be 0): rocPRIM's single-pass look-back scan
-static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
-    SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, bytes + 64));
-    HIPCHK(rocprim::exclusive_scan(ctx->scan_tmp.p, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
-    return SPHX_OK;
-}
-
-int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n) { return excl_scan_plus_total(ctx, in, out, n); }
 
 // three-phase exclusive scan of int32: 2048 items per block
 #define SCAN_ITEMS 8
@@ -280,6 +270,110 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total_out) {
     *total_out = tot;
     return woff + incl - v;
 }
+
+// ---- exclusive scan of n ints, out[n] = total (in[n] must be 0): ONE launch ------------------------------------------
+// Single-pass scan.  A tile of 4096 items publishes its sum, adds up the sums of all earlier tiles (a few hundred words, a
+// few per thread) and writes its items: a tile waits for sums only, which no tile waits to publish, and the launcher
+// keeps the grid small enough for every tile to be resident at once (<= LBS_MAXTILES; larger scans take rocPRIM's) - so
+// there is no chain from tile to tile, no ticket and no order to keep.  A word is {epoch x 4 + 1, sum} in 64 bits, read
+// and written whole at agent scope: words of earlier launches carry another epoch and read as "not yet", so nothing is
+// reset between launches (rocPRIM's look-back scan orders its tiles by a ticket on one address and resets its tile states
+// with a launch of its own: 6 us + 13 us per scan at 2.4e6 cells, twice per step).
+#define LBS_ITEMS 16
+#define LBS_TILE (LBS_ITEMS * 256)
+#define LBS_MAXTILES 1024          // 256 CUs x 8 workgroups of 256 threads fit at once: half of that
+__global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, const int* __restrict__ in, int* __restrict__ out,
+                                                            u64* state, int* ctr, unsigned epoch, int ntiles) {
+    __shared__ int s_prefix;
+    const int tile = blockIdx.x;          // (every tile of a launch is resident at once - the launcher sees to it - so any order will do)
+    const int base = tile * LBS_TILE + threadIdx.x * LBS_ITEMS;
+    int v[LBS_ITEMS];
+    int s = 0;
+    if (base + LBS_ITEMS <= n_items) {
+#pragma unroll
+        for (int q = 0; q < LBS_ITEMS; q += 4) {
+            const int4 t = *reinterpret_cast<const int4*>(in + base + q);
+            v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < LBS_ITEMS; ++q) v[q] = (base + q < n_items) ? in[base + q] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < LBS_ITEMS; ++q) s += v[q];
+    int tot;
+    int ex = block_exclusive_scan(s, &tot);
+    // publish the tile's sum, then add up the sums of ALL earlier tiles (each thread a few of them: a tile waits for sums
+    // only, which no tile waits to publish - no chain from tile to tile)
+    const u64 tag = ((u64)epoch << 2) | 1ull;
+    if (threadIdx.x == 0) __hip_atomic_store(&state[tile], (tag << 32) | (u32)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int part = 0;
+    for (int j = threadIdx.x; j < tile; j += 256) {
+        for (unsigned spins = 0;;) {
+            const u64 w = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 32) == tag) { part += (int)(u32)w; break; }
+            // (tile j took its ticket before this one: it is running and publishes without waiting for anybody; the bound
+            //  is there so that a broken invariant shows as wrong numbers and a raised flag, ctr[2], not as a hung device)
+            if (++spins > (1u << 22)) { ctr[2] = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    part = wave_sum(part);
+    __shared__ int s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) s_prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    ex += s_prefix;
+    if (base + LBS_ITEMS <= n_items) {
+#pragma unroll
+        for (int q = 0; q < LBS_ITEMS; q += 4) {
+            int4 t;
+            t.x = ex; ex += v[q]; t.y = ex; ex += v[q + 1]; t.z = ex; ex += v[q + 2]; t.w = ex; ex += v[q + 3];
+            *reinterpret_cast<int4*>(out + base + q) = t;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < LBS_ITEMS; ++q) { if (base + q < n_items) out[base + q] = ex; ex += v[q]; }
+    }
+}
+static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
+    if (ctx->scan_rocprim || (((uintptr_t)in | (uintptr_t)out) & 15)) {
+        size_t bytes = 0;
+        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+        SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, bytes + 64));
+        HIPCHK(rocprim::exclusive_scan(ctx->scan_tmp.p, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+        return SPHX_OK;
+    }
+    const int n_items = n + 1;
+    const int ntiles = (n_items + LBS_TILE - 1) / LBS_TILE;
+    if (ntiles > LBS_MAXTILES) {
+        size_t bytes = 0;
+        HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+        SPHX_TRY(sphx_ensure(ctx, ctx->scan_tmp, bytes + 64));
+        HIPCHK(rocprim::exclusive_scan(ctx->scan_tmp.p, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
+        return SPHX_OK;
+    }
+    // (one set of tile words per stream the scans are launched on: launches on ONE stream are ordered, two streams are not)
+    const int which = (ctx->stream == ctx->own_stream) ? 0 : 1;
+    DevBuf& st = ctx->lbs_state[which];
+    const size_t need = ((size_t)LBS_MAXTILES + 8) * sizeof(u64);          // (one size for every scan: nothing to allocate later, e.g. while a step graph is recorded)
+    if (st.cap < need) {
+        SPHX_TRY(sphx_ensure(ctx, st, need));
+        HIPCHK(hipMemsetAsync(st.p, 0, st.cap, ctx->stream));
+    }
+    // (a recorded launch is replayed with the epoch it was recorded with: its words are cleared by a node of the graph)
+    if (ctx->capturing) HIPCHK(hipMemsetAsync(st.as<u64>() + 2, 0, (size_t)ntiles * sizeof(u64), ctx->stream));
+    unsigned& ep = ctx->lbs_epoch[which];
+    ep = (ep + 1u) & 0x3FFFFFFFu;
+    if (ep == 0u) ep = 1u;
+    hipLaunchKernelGGL(lookback_scan_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n_items, in, out,
+                       st.as<u64>() + 2, st.as<int>(), ep, ntiles);
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
+}
+
+int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n) { return excl_scan_plus_total(ctx, in, out, n); }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase1(int n, const int* in, int* block_sums) {
     int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
