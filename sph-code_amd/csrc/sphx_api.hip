@@ -1127,6 +1127,14 @@ extern "C" int sphx_get_stats(sphx_ctx* ctx, sphx_stats* out) {
         SPHX_TRY(sphx_badc_read(ctx));
     }
     *out = ctx->stats;
+    // the grid build's single-launch scan bounds its waits; a wait that ran out raised a flag (and left wrong numbers)
+    for (int w = 0; w < 2; ++w) {
+        if (!ctx->lbs_state[w].p) continue;
+        int flag = 0;
+        HIPCHK(hipSetDevice(ctx->device));
+        HIPCHK(hipMemcpy(&flag, ctx->lbs_state[w].as<int>() + 2, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag) return sphx_set_err(ctx, SPHX_E_STATE, "lookback_scan_kernel: a tile's sum never arrived (results since then are wrong)");
+    }
     return SPHX_OK;
 }
 extern "C" int sphx_set_timing_detail(sphx_ctx* ctx, int on) {
