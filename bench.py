@@ -200,8 +200,11 @@ def main():
     ms_step = dt / args.steps * 1e3
     value = args.n * args.steps / dt
     ms_search = st["ms_search"] / max(st["search_steps"], 1)      # HIP events on the library's stream, around the search launches
-    # (of the steps that carry them: replays of a step graph - small N - do not)
-    achieved = B_SEARCH * args.n / (ms_search * 1e-3) / 1e9
+    # (of the steps that carry them: replays of a step graph - SPHX_GRAPH - do not; when every timed step was a replay the
+    #  detail steps after them, which are real steps, supply the figure)
+    if not ms_search > 0.0:
+        ms_search = st_detail["ms_search"] / max(st_detail["search_steps"], 1)
+    achieved = B_SEARCH * args.n / (ms_search * 1e-3) / 1e9 if ms_search > 0.0 else None
     tag = workload_tag(args.workload, args.forms, args.species, args.drag)
     prof = search_profile(tag, args.n, args.k)
     # the a6-inclusive figure beside the core one (nsc.hydro_update always forms F[s,i], nsc:624-627; the headline's step
@@ -219,7 +222,7 @@ def main():
         sp.ctx.close()
         del sp
     ipq = prof.get("valu_wave_instr_per_query")
-    valu_achieved = (ipq * args.n / (ms_search * 1e-3) / 1e9) if ipq else None
+    valu_achieved = (ipq * args.n / (ms_search * 1e-3) / 1e9) if (ipq and ms_search > 0.0) else None
     b_step = B_STEP_SPECIES if args.species else B_STEP_CORE
     out = {
         "metric": "particle-steps/sec + achieved HBM GB/s, 10^6-particle 3D sphere, 1/2/4/8 GPUs",
@@ -264,7 +267,7 @@ def main():
                      "l2_hit_rate": prof.get("l2_hit_rate"),
                      "profiled_counters_source": prof.get("source", None),
                      "kernel_ms": ms_search,
-                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                              "algorithmic_bytes_per_launch": B_SEARCH * args.n, "algorithmic_bytes_per_particle": B_SEARCH,
                              "traffic": prof.get("traffic_bytes_per_launch")}},
         "step_model": {"algorithmic_bytes_per_particle_step": b_step,
