@@ -34,12 +34,8 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// The tile holds the candidates in PAIRS, laid out for packed fp32 arithmetic (v_pk_add/mul/fma_f32 work on
-// two candidates at once) and for whole-width LDS reads:  tile_xy[pair] = {x0, x1, y0, y1},
-// tile_zi[pair] = {z0, z1, index0, index1}.  Phase A reads one b128 + one b64 per pair (3 LDS cycles per
-// candidate; a 12-byte read of an {x,y,z,idx} record would cost 8).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((aligned(16))) TileZI { float z0, z1; int i0, i1; };
+// The tile holds the candidates as four arrays by slot (x, y, z, index): the matrix-core form of phase A, the keys and
+// the output read single slots; the packed-fp32 form of phase A reads the pairs (2 w, 2 w + 1) as three 8-byte loads.
 
 // wave-wide min / max of doubles: lane exchanges by DPP inside the rows of 16 (sphx_wave.h xchg32), one ds_swizzle
 // and one bpermute for the last two steps
@@ -168,12 +164,14 @@ __device__ __forceinline__ f16x8 kg_query_frag(float sx, float sy, float sz, flo
     return __builtin_bit_cast(f16x8, make_uint4(w0, w1, w2, w3));
 }
 __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArgs a) {
-    __shared__ f32x4 tile_xy[KG_TCAP / 2];
-    __shared__ TileZI tile_zi[KG_TCAP / 2];
-    float* txy = reinterpret_cast<float*>(tile_xy);
-    float* tzi = reinterpret_cast<float*>(tile_zi);
-    // slot t: x at txy[(t >> 1) * 4 + (t & 1)], y two floats on; z, index likewise in tzi
-#define KG_OFF(t) ((((t) >> 1) << 2) | ((t) & 1))
+    // the tile: four arrays by slot (x, y, z relative to the group's centre in cell units, storage index).  (Until the matrix
+    // cores took phase A the candidates lay in pairs {x0,x1,y0,y1}{z0,z1,i0,i1} for packed math: every other access paid
+    // three instructions for the offset.)
+    __shared__ __attribute__((aligned(16))) float tile_soa[4 * KG_TCAP];
+    float* tx = tile_soa;
+    float* ty = tile_soa + KG_TCAP;
+    float* tz = tile_soa + 2 * KG_TCAP;
+    int* ti = reinterpret_cast<int*>(tile_soa + 3 * KG_TCAP);
     __shared__ unsigned short slist[64 * 64];       // [slot][query]: tile slots inside the query's radius;
                                                     // while staging: row of each slot (u8) + the rows' bases
     static_assert(KG_TPRE * 2 + KG_MAXROWS * 4 <= 64 * 64 * 2, "slot->row ids + row bases share the list's memory");
@@ -350,9 +348,8 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
                     }
                     const int slot = base + lanes_below(km);
                     if (keep && slot < KG_TCAP) {
-                        const int o = KG_OFF(slot);
-                        txy[o] = rx; txy[o + 2] = ry; tzi[o] = rz;
-                        reinterpret_cast<int*>(tzi)[o + 2] = pp[u];
+                        tx[slot] = rx; ty[slot] = ry; tz[slot] = rz;
+                        ti[slot] = pp[u];
                     }
                 }
             }
@@ -366,11 +363,11 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             // pad the tile to whole mask words with records nobody accepts
             const int nwp = (T + 31) >> 5;
             if (tid < nwp * 32 - T) {
-                const int o = KG_OFF(T + tid);
+                const int o = T + tid;
                 // (matrix-core form: finite in fp16, |c|^2 = 16875 < 65504, and >= 35 cells from every query on each axis)
                 const float padv = use_mfma ? 75.0f : 1e30f;
-                txy[o] = padv; txy[o + 2] = padv; tzi[o] = padv;
-                reinterpret_cast<int*>(tzi)[o + 2] = -1;
+                tx[o] = padv; ty[o] = padv; tz[o] = padv;
+                ti[o] = -1;
             }
         }
     }
@@ -424,8 +421,8 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         //   rows 8 a + b (b < 4, accumulator registers of lanes 0..31)  -> slots 4 a + b,  rows 8 a + 4 + b -> 16 + 4 a + b
         const int pi32 = ((n32 & 4) << 2) | ((n32 >> 3) << 2) | (n32 & 3);
         for (int w = wave; w < nw; w += 4) {
-            const int o = KG_OFF(w * 32 + pi32);
-            const float cx = txy[o], cy = txy[o + 2], cz = tzi[o];
+            const int o = w * 32 + pi32;
+            const float cx = tx[o], cy = ty[o], cz = tz[o];
             const f16x8 Ac = kg_cand_frag(cx, cy, cz, hh);
             const f32x16 D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[0], zero16, 0, 0, 0);
             const f32x16 D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac, Bq[1], zero16, 0, 0, 0);
@@ -459,17 +456,18 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             u32 m = 0;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                f32x4 A[8];
-                f32x2 Z[8];
+                f32x2 X[8], Y[8], Z[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    A[j] = tile_xy[w * 16 + hh * 8 + j];
-                    Z[j] = *reinterpret_cast<const f32x2*>(&tile_zi[w * 16 + hh * 8 + j]);
+                    const int o = 2 * (w * 16 + hh * 8 + j);               // the pair of slots o, o + 1
+                    X[j] = *reinterpret_cast<const f32x2*>(&tx[o]);
+                    Y[j] = *reinterpret_cast<const f32x2*>(&ty[o]);
+                    Z[j] = *reinterpret_cast<const f32x2*>(&tz[o]);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     // d2 - r2 accumulated from -r2 (three packed fmas for two candidates); negative = inside
-                    const f32x2 dx = A[j].xy - qx2, dy = A[j].zw - qy2, dz = Z[j] - qz2;
+                    const f32x2 dx = X[j] - qx2, dy = Y[j] - qy2, dz = Z[j] - qz2;
                     f32x2 e2 = __builtin_elementwise_fma(dx, dx, nr2);
                     e2 = __builtin_elementwise_fma(dy, dy, e2);
                     e2 = __builtin_elementwise_fma(dz, dz, e2);
@@ -541,8 +539,8 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
             float cx[8], cy[8], cz[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int o = KG_OFF(tt[u] & 2047);
-                cx[u] = txy[o]; cy[u] = txy[o + 2]; cz[u] = tzi[o];
+                const int o = tt[u] & 2047;
+                cx[u] = tx[o]; cy[u] = ty[o]; cz[u] = tz[o];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -683,12 +681,12 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
     KG_STAMP(5)
     // ---- outputs: rank r = 16 part + u ----
     {
-        const int* tidx = reinterpret_cast<const int*>(tzi);
+        const int* tidx = ti;
         const bool wr = pq < a.npad && (okq || !q_isq);    // failed queries are written by the list-mode launch that
                                                             // follows; non-queries (ghosts, padding) get -1
         int idx[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) idx[u] = (part * 16 + u < K) ? tidx[KG_OFF(okq ? (key[u] & 2047u) : 0u) + 2] : -1;
+        for (int u = 0; u < 16; ++u) idx[u] = (part * 16 + u < K) ? tidx[okq ? (key[u] & 2047u) : 0u] : -1;
         // the K-th neighbour's exact distance: its loads go out before the row stores
         const int rl = K - 1;
         int lastidx = -1;
@@ -715,7 +713,7 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
 #pragma unroll
             for (int u = 0; u < 15; ++u) {
                 if ((mine16 >> u) & 1u) {
-                    a.tie_list[base] = make_int4(pq, part * 16 + u, tidx[KG_OFF(key[u] & 2047u) + 2], tidx[KG_OFF(key[u + 1] & 2047u) + 2]);
+                    a.tie_list[base] = make_int4(pq, part * 16 + u, tidx[key[u] & 2047u], tidx[key[u + 1] & 2047u]);
                     ++base;
                 }
             }
