@@ -117,6 +117,9 @@ struct KgShared {
 #ifndef KG_MINWAVES
 #define KG_MINWAVES 5
 #endif
+#ifndef KG_STAGE_U
+#define KG_STAGE_U 2                 // candidates per thread whose loads are in flight together while the tile is staged
+#endif
 #ifndef KG_MFMA
 #define KG_MFMA 1                    // phase A on the matrix cores where its error bound allows
 #endif
@@ -321,21 +324,22 @@ __global__ __launch_bounds__(256, KG_MINWAVES) void knn_group_kernel(KnnGroupArg
         // by cells: a quarter fewer slots for phase A), the kept ones compacted per wave (ballot + one LDS add). ----
         if (group_ok) {
             const float hx = sh.hx, hy = sh.hy, hz = sh.hz, rc2 = sh.rc2;
-            for (int t0 = 0; t0 < T; t0 += 512) {
-                int pp[2];
+            for (int t0 = 0; t0 < T; t0 += 256 * KG_STAGE_U) {
+                int pp[KG_STAGE_U];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < KG_STAGE_U; ++u) {
                     const int t = t0 + 256 * u + tid;
                     pp[u] = t < T ? rowbase[rowof[t]] + t : -1;
                 }
-                double X[2], Y[2], Z[2];
+                double X[KG_STAGE_U], Y[KG_STAGE_U], Z[KG_STAGE_U];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < KG_STAGE_U; ++u) {
                     const int q = pp[u] >= 0 ? pp[u] : 0;
                     X[u] = a.x[q]; Y[u] = a.y[q]; Z[u] = a.z[q];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < KG_STAGE_U; ++u) {
+                    if (256 * u >= T - t0) break;                 // (uniform: nothing left for this and the later slots)
                     const float rx = (float)((X[u] - Ox) * g.inv_cell), ry = (float)((Y[u] - Oy) * g.inv_cell),
                                 rz = (float)((Z[u] - Oz) * g.inv_cell);
                     const float ex = fmaxf(fabsf(rx) - hx, 0.0f), ey = fmaxf(fabsf(ry) - hy, 0.0f), ez = fmaxf(fabsf(rz) - hz, 0.0f);
