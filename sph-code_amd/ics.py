@@ -155,7 +155,8 @@ def loop_d(state, k=40, sample=200000):
     pts = state["points"]
     n = len(pts)
     sub = pts[:: max(1, n // sample)]
-    hs = cKDTree(sub).query(sub, k=min(k, len(sub)))[0][:, -1] * (len(sub) / n) ** (1. / 3.)
+    dd = cKDTree(sub).query(sub, k=min(k, len(sub)))[0]                    # (k = 1: a 1-d array of zeros - the particle itself)
+    hs = np.asarray(dd).reshape(len(sub), -1)[:, -1] * (len(sub) / n) ** (1. / 3.)
     return float(np.median(hs) / np.median((state["mass"] / 10 ** 1.5 / SOLAR) ** (1. / 3.)))
 
 
