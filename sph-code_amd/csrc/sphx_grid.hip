@@ -281,16 +281,17 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total_out) {
 }
 
 // ---- exclusive scan of n ints, out[n] = total (in[n] must be 0): ONE launch ------------------------------------------
-// Single-pass scan.  A tile of 4096 items publishes its sum, adds up the sums of all earlier tiles (a few hundred words, a
+// Single-pass scan.  A tile of 8192 items publishes its sum, adds up the sums of all earlier tiles (a few hundred words, a
 // few per thread) and writes its items: a tile waits for sums only, which no tile waits to publish, and the launcher
 // keeps the grid small enough for every tile to be resident at once (<= LBS_MAXTILES; larger scans take rocPRIM's) - so
 // there is no chain from tile to tile, no ticket and no order to keep.  A word is {epoch x 4 + 1, sum} in 64 bits, read
 // and written whole at agent scope: words of earlier launches carry another epoch and read as "not yet", so nothing is
 // reset between launches (rocPRIM's look-back scan orders its tiles by a ticket on one address and resets its tile states
 // with a launch of its own: 6 us + 13 us per scan at 2.4e6 cells, twice per step).
-#define LBS_ITEMS 16
+#define LBS_ITEMS 32
 #define LBS_TILE (LBS_ITEMS * 256)
-#define LBS_MAXTILES 1024          // 256 CUs x 8 workgroups of 256 threads fit at once: half of that
+#define LBS_MAXTILES 512           // 256 CUs x 8 workgroups of 256 threads fit at once: a quarter of that, so that four
+                                   // processes sharing a device (rehearsals of several ranks on one GPU) still fit together
 __global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, const int* __restrict__ in, int* __restrict__ out,
                                                             u64* state, int* ctr, unsigned epoch, int ntiles) {
     __shared__ int s_prefix;
