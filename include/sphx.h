@@ -106,6 +106,11 @@ const char* sphx_tunables(const sphx_ctx* ctx);
  * search forms them, compared with fp64.  max_err_over_E2: the largest |D - (d^2 - R^2 (1 + pad))| / E^2 met; kappa: the
  * bound the search's certification assumes; wrong_signs: entries beyond that bound whose sign differed (must be 0).
  * Test infrastructure (tests/test_gpu_parity.py); replaces nothing in the reference. */
+/* Self-test of the grid build's single-launch prefix sum (sphx_grid.hip: lookback_scan_kernel) against rocPRIM's scan on
+ * the device: n pseudo-random counts through both, entries that differ in *mismatches (must be 0); *single_launch: whether
+ * n ran through the single-launch form (scans of more than 512 tiles of 8192 items take rocPRIM's either way).
+ * Test infrastructure; replaces nothing in the reference. */
+int sphx_selftest_scan(sphx_ctx* ctx, int n, unsigned seed, long long* mismatches, int* single_launch);
 int sphx_selftest_mfma_cull(sphx_ctx* ctx, double E, int blocks, unsigned seed, double* max_err_over_E2,
                             double* wrong_signs, double* kappa);
 /* Page-locked host memory for the big arrays the array entry points hand back ((N,K) int64 + float64 from

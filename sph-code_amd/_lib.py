@@ -43,6 +43,7 @@ SIGNATURES = {
     "sphx_version": (C.c_int, []),
     "sphx_build_info": (C.c_char_p, []),
     "sphx_tunables": (C.c_char_p, [_P]),
+    "sphx_selftest_scan": (C.c_int, [_P, C.c_int, C.c_uint, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "sphx_selftest_mfma_cull": (C.c_int, [_P, C.c_double, C.c_int, C.c_uint, _D, _D, _D]),
     "sphx_host_alloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "sphx_host_free": (C.c_int, [_P]),

@@ -385,6 +385,54 @@ static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
 
 int sphx_excl_scan_int(sphx_ctx* ctx, const int* in, int* out, int n) { return excl_scan_plus_total(ctx, in, out, n); }
 
+// ---- self-test of the single-launch scan against rocPRIM's on the device (tests/test_gpu_parity.py) ----
+__global__ void scan_selftest_fill(int n, unsigned seed, int* in) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        unsigned v = (unsigned)i * 2654435761u + seed * 40503u;
+        v ^= v >> 15; v *= 2246822519u; v ^= v >> 13;
+        in[i] = (i < n) ? (int)(v & 7u) : 0;                  // (in[n] = 0: the scan's contract)
+    }
+}
+__global__ void scan_selftest_cmp(int n, const int* a, const int* b, unsigned long long* bad) {
+    unsigned long long c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) c += (a[i] != b[i]) ? 1ull : 0ull;
+    if (c) atomicAdd(bad, c);
+}
+extern "C" int sphx_selftest_scan(sphx_ctx* ctx, int n, unsigned seed, long long* mismatches, int* single_launch) {
+    if (!ctx || !mismatches || n < 1) return sphx_set_err(ctx, SPHX_E_ARG, "sphx_selftest_scan: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf in, o1, o2, bad;
+    int rc = SPHX_OK;
+    do {
+        if ((rc = sphx_ensure(ctx, in, ((size_t)n + 8) * sizeof(int))) != SPHX_OK) break;
+        if ((rc = sphx_ensure(ctx, o1, ((size_t)n + 8) * sizeof(int))) != SPHX_OK) break;
+        if ((rc = sphx_ensure(ctx, o2, ((size_t)n + 8) * sizeof(int))) != SPHX_OK) break;
+        if ((rc = sphx_ensure(ctx, bad, 64)) != SPHX_OK) break;
+        hipLaunchKernelGGL(scan_selftest_fill, dim3(1024), dim3(256), 0, ctx->stream, n, seed, in.as<int>());
+        if (hipMemsetAsync(bad.p, 0, 8, ctx->stream) != hipSuccess) { rc = SPHX_E_HIP; break; }
+        const bool keep = ctx->scan_rocprim;
+        ctx->scan_rocprim = false;
+        rc = excl_scan_plus_total(ctx, in.as<int>(), o1.as<int>(), n);
+        ctx->scan_rocprim = true;
+        if (rc == SPHX_OK) rc = excl_scan_plus_total(ctx, in.as<int>(), o2.as<int>(), n);
+        ctx->scan_rocprim = keep;
+        if (rc != SPHX_OK) break;
+        hipLaunchKernelGGL(scan_selftest_cmp, dim3(1024), dim3(256), 0, ctx->stream, n, o1.as<int>(), o2.as<int>(),
+                           bad.as<unsigned long long>());
+        unsigned long long h = 0;
+        if (hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPHX_E_HIP; break; }
+        *mismatches = (long long)h;
+        if (single_launch) *single_launch = ((n + 1 + LBS_TILE - 1) / LBS_TILE <= LBS_MAXTILES) ? 1 : 0;
+    } while (false);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (in.p) (void)hipFree(in.p);
+    if (o1.p) (void)hipFree(o1.p);
+    if (o2.p) (void)hipFree(o2.p);
+    if (bad.p) (void)hipFree(bad.p);
+    return rc;
+}
+
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase1(int n, const int* in, int* block_sums) {
     int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     int s = 0;

@@ -1181,3 +1181,20 @@ def test_matrix_core_cull_stays_inside_its_error_bound(E):
     print("E = %g: max |D - exact| / E^2 = %.3g (bound %.3g), wrong signs %g" % (E, worst.value, kappa.value, wrong.value))
     assert 0.0 < worst.value <= kappa.value
     assert wrong.value == 0.0
+
+
+@pytest.mark.parametrize("n", [1, 255, 8191, 8192, 8193, 1000001, 512 * 8192 - 1, 512 * 8192 + 5])
+def test_single_launch_scan_equals_rocprim(n):
+    """The grid build's two prefix sums (cell starts, blob order: what nsc.neighbors' tree build is replaced by) run as one
+    launch each: every tile publishes its sum under the launch's epoch and adds up the sums of all tiles before it.  The
+    library runs pseudo-random counts through it and through rocPRIM's scan and compares on the device - at one item, at
+    the tile boundary, at the headline's size, at the last size the single-launch form takes and just beyond it."""
+    import ctypes as C
+    from sph_code_amd import _lib
+    ctx = _lib.Context()
+    bad, single = C.c_longlong(-1), C.c_int(-1)
+    for seed in (1, 2, 3):                                  # (three launches in a row: the words of earlier launches must read as stale)
+        rc = ctx.lib.sphx_selftest_scan(ctx.h, n, seed, C.byref(bad), C.byref(single))
+        assert rc == 0
+        assert bad.value == 0, (n, seed, bad.value)
+    assert single.value == (1 if n + 1 <= 512 * 8192 else 0)
