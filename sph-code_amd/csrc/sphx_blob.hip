@@ -48,6 +48,7 @@ __global__ __launch_bounds__(BLOB_T) void blob_dedup_kernel(int n, int npad, int
                                                             int* uniq, const int* __restrict__ qorder,
                                                             const int* __restrict__ omap, int n_active,
                                                             unsigned char* bclass) {
+    __builtin_amdgcn_s_setprio(DEDUP_PRIO);      // ahead of the record build that streams beside it on the other stream: this kernel is the one the passes wait for (step -13 us)
     extern __shared__ u16 dd_tile[];              // [k][BLOB_P] entry / slot numbers
     __shared__ int key[DD_TAB];
     __shared__ u16 slot_of[DD_TAB];
