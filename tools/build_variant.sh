@@ -7,7 +7,8 @@ OBJ="$ROOT/variants_tmp/obj_$NAME"
 mkdir -p "$OBJ"
 pids=()
 for src in "$ROOT"/sph-code_amd/csrc/*.hip; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w "$@" -c -o "$OBJ/$(basename "$src" .hip).o" "$src" &
+  ff=""; [ "$(basename "$src")" = "sphx_knn_group.hip" ] && ff="-mllvm -amdgpu-sched-strategy=max-memory-clause"    # (as sph-code_amd/build.py FILE_FLAGS)
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $ff "$@" -c -o "$OBJ/$(basename "$src" .hip).o" "$src" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p" || { echo "compile failed"; exit 1; }; done
