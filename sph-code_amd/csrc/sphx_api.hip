@@ -81,6 +81,16 @@ extern "C" int sphx_host_free(void* p) {
     return SPHX_OK;
 }
 
+// The step's main stream and its side stream (state permutation's second half, record build, h sums, read-backs).
+// The main stream at the device's highest priority, the side stream at its lowest: what the step waits for is dispatched
+// first (step 1.257 -> 1.242 ms, four runs each; SPHX_STREAM_PRIO=0: both at the default priority).
+static hipError_t sphx_stream_create(hipStream_t* st, int side, bool prio) {
+    if (!prio) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, side ? least : greatest);
+}
+
 extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (!out) return SPHX_E_ARG;
     *out = nullptr;
@@ -128,6 +138,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = env("SPHX_BLOB_SPLIT")) ctx->blob_split_on = atoi(e) != 0;
     if (const char* e = env("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
     if (const char* e = env("SPHX_TIE_FIX")) ctx->tie_fix = atoi(e) != 0;
+    if (const char* e = env("SPHX_STREAM_PRIO")) ctx->stream_prio = atoi(e) != 0;
     if (const char* e = env("SPHX_SCAN_ROCPRIM")) ctx->scan_rocprim = atoi(e) != 0;
     if (const char* e = env("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = env("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto
@@ -159,7 +170,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     (void)env("SPHX_KG_EXP_NOAMB"); (void)env("SPHX_KG_PROF");       // (read where they act, sphx_knn_group.hip; recorded here)
 #endif
     bool ok = hipSetDevice(device) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              sphx_stream_create(&ctx->stream, 0, ctx->stream_prio) == hipSuccess &&
               hipHostMalloc(&ctx->pinned, 16384, hipHostMallocDefault) == hipSuccess;
     ctx->own_stream = ctx->stream;
     for (int i = 0; ok && i < 10; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
@@ -168,7 +179,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     for (int r = 0; ok && r < 2; ++r)
         ok = hipEventCreateWithFlags(&ctx->lag_bev[r], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->lag_hev[r], hipEventDisableTiming) == hipSuccess;
-    if (ok) ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
+    if (ok) ok = sphx_stream_create(&ctx->side_stream, 1, ctx->stream_prio) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->ev_perm_fork, hipEventDisableTiming) == hipSuccess &&
