@@ -139,6 +139,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = env("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
     if (const char* e = env("SPHX_TIE_FIX")) ctx->tie_fix = atoi(e) != 0;
     if (const char* e = env("SPHX_STREAM_PRIO")) ctx->stream_prio = atoi(e) != 0;
+    if (const char* e = env("SPHX_BB_DIRECT")) ctx->bb_direct = atoi(e) != 0;
     if (const char* e = env("SPHX_SCAN_ROCPRIM")) ctx->scan_rocprim = atoi(e) != 0;
     if (const char* e = env("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
     if (const char* e = env("SPHX_HINT_DISTRUST")) ctx->distrust_mode = atoi(e);     // 0 never, 1 always, 2 auto

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int n, const int* in, 
 // not by anything before this kernel, so they need no launch of their own on the way (early blocks: off the kernel's tail).
 __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, const int* cell_start,
                                                     int* fill, int* perm, int bb_nblocks, const double* bb_part,
-                                                    double* bb_out) {
+                                                    double* bb_out, double* bb_host) {
     __shared__ double sw[4];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, c
         __syncthreads();
         if (threadIdx.x == 0) {
             const double a0 = sw[0], a1 = sw[1], a2 = sw[2], a3 = sw[3];
-            bb_out[c] = c < 3 ? fmin(fmin(a0, a1), fmin(a2, a3)) : (c < 6 ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3));
+            const double r_ = c < 3 ? fmin(fmin(a0, a1), fmin(a2, a3)) : (c < 6 ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3));
+            bb_out[c] = r_;
+            if (bb_host) bb_host[c] = r_;          // (pinned host memory, read by the next step's host code behind an event: no copy launch)
         }
     }
 }
@@ -760,11 +762,16 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
                            ctx->cell_of.as<int>(), fill);
     }
     SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc));
+    // (the statistics folded by the scatter's first blocks go straight to the pinned slot the next step's host code reads:
+    //  the 104-byte copy that followed was a launch of its own on the step's stream, 5 us + its gaps)
+    const bool to_host = bb_fold_part != nullptr && bb_fold_out && !ctx->capturing && pb >= BB_W && ctx->bb_direct;
+    double* bb_host = to_host ? reinterpret_cast<double*>((char*)ctx->pinned + LAG_OFF + 512 * lag_cur) : nullptr;
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out);
+                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out, bb_host);
     if (bb_fold_out && !ctx->capturing) {
         char* slot = (char*)ctx->pinned + LAG_OFF;
-        HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, bb_fold_out, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (!to_host)
+            HIPCHK(hipMemcpyAsync(slot + 512 * lag_cur, bb_fold_out, BB_W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->step_ev1) {
             ctx->lag_balias[lag_cur] = ctx->step_ev1;          // recorded by the caller a few launches on, before the search
         } else {

@@ -225,6 +225,7 @@ struct sphx_ctx {
     int64_t farq_last = 0;          // far queries met by the previous hinted search
     DevBuf lbs_state[2];                   // tile words of the look-back scan (sphx_grid.hip), per launching stream
     unsigned lbs_epoch[2] = {0u, 0u};
+    bool bb_direct = true;                 // the grid build's box statistics written to pinned memory by the kernel that folds them
     bool stream_prio = true;               // main stream at the highest, side stream at the lowest device priority
     bool scan_rocprim = false;             // SPHX_SCAN_ROCPRIM=1: rocPRIM's scan instead
     DevBuf tie_list;                       // int4 {query slot, rank, index a, index b}: near ties the grouped search leaves to the list-mode launch's tie blocks
