@@ -139,6 +139,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = env("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
     if (const char* e = env("SPHX_TIE_FIX")) ctx->tie_fix = atoi(e) != 0;
     if (const char* e = env("SPHX_STREAM_PRIO")) ctx->stream_prio = atoi(e) != 0;
+    if (const char* e = env("SPHX_SPECIES_FUSED")) ctx->species_fused = atoi(e) != 0;
     if (const char* e = env("SPHX_BB_DIRECT")) ctx->bb_direct = atoi(e) != 0;
     if (const char* e = env("SPHX_SCAN_ROCPRIM")) ctx->scan_rocprim = atoi(e) != 0;
     if (const char* e = env("SPHX_SPECIES_LDS")) ctx->species_lds = atoi(e) != 0;
@@ -740,12 +741,35 @@ static int one_step(sphx_ctx* ctx, int k, double dist, int first, double fixed_d
     }
     if (detail) HIPCHK(hipEventRecord(ev[3], ctx->stream));
     ctx->lean_outputs = true;          // (nothing in the step reads G: hydro_accel = G / rho is what the update takes)
-    const int rc_dens = sphx_pass_density(ctx, n, k);
+    // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un -
+    // inside pass 1's kernel where both run out of LDS (their first sweeps are the same), else behind it
+    const bool species = ctx->s > 0 && ctx->fun_id.p;
+    const bool sp_fused = species && ctx->species_fused && ctx->species_lds && ctx->use_lds && ctx->qorder && ctx->blob_lists &&
+                          !ctx->map_perm && ctx->sp == 16 && ctx->s <= 16 && k <= SPHX_MAX_K;
+    int rc_dens;
+    if (sp_fused) {
+        const int S = ctx->s;
+        rc_dens = sphx_ensure(ctx, ctx->rho, (size_t)n * sizeof(double));
+        if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->rhod, (size_t)n * sizeof(double));
+        if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->nden, (size_t)n * sizeof(double));
+        if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->G, (size_t)n * 3 * sizeof(double));
+        if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->ha, (size_t)n * 3 * sizeof(double));
+        if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->F, (size_t)n * S * sizeof(double));
+        if (rc_dens == SPHX_OK && ctx->agb_on) {
+            rc_dens = sphx_ensure(ctx, ctx->Zmet, (size_t)n * sizeof(double));
+            if (rc_dens == SPHX_OK) rc_dens = sphx_ensure(ctx, ctx->agb_dust, (size_t)n * S * sizeof(double));
+        }
+        if (rc_dens == SPHX_OK)
+            rc_dens = sphx_blob_density_species(ctx, n, k, S, ctx->fun_id.as<double>(), ctx->st.id.as<int>(), ctx->st.m.as<double>(),
+                                                ctx->F.as<double>(), ctx->Zmet.as<double>(), ctx->agb_dust.as<double>(),
+                                                (ctx->agb_on && ctx->Zmet.p && ctx->agb_dust.p) ? 1 : 0);
+    } else {
+        rc_dens = sphx_pass_density(ctx, n, k);
+    }
     ctx->lean_outputs = false;
     SPHX_TRY(rc_dens);
     if (detail) HIPCHK(hipEventRecord(ev[9], ctx->stream));
-    // nsc:624-627 on the step's list (+ metallicity and AGB yields when a table is set): when the state carries f_un
-    if (ctx->s > 0 && ctx->fun_id.p) SPHX_TRY(sphx_step_species(ctx, n, k));
+    if (species && !sp_fused) SPHX_TRY(sphx_step_species(ctx, n, k));
     if (detail) HIPCHK(hipEventRecord(ev[4], ctx->stream));
     SPHX_TRY(sphx_pass_pi(ctx, n, k, s.hprev.as<double>(), s.ptype.as<double>()));
     if (detail) HIPCHK(hipEventRecord(ev[5], ctx->stream));

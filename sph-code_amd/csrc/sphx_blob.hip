@@ -235,11 +235,12 @@ int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k) {
 // each of them (the usual case): straight-line LDS reads and arithmetic, nothing to branch on.
 // Otherwise a position may be empty (skipped) or unstaged (fetched through the int32 list).
 struct DensAcc { double rho, rd, n, gx, gy, gz; };
-template <bool FAST, bool CLIP>
+// WOUT: the batch's species weights Nw_j W_ij (nsc:626) are handed back as well (0 where the list has no neighbour)
+template <bool FAST, bool CLIP, bool WOUT = false>
 __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[NB], const double2* img,
                                               const RecA* __restrict__ rec, const int* __restrict__ nbr,
                                               size_t col0, size_t colstep, double xr, double yr, double zr,
-                                              double hi2, double ci, double Ai) {
+                                              double hi2, double ci, double Ai, double* wout = nullptr) {
     Q4 q0b[NB], q1b[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -252,6 +253,7 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
     if (FAST) __builtin_amdgcn_sched_barrier(0);       // all of the batch's LDS reads are issued before its arithmetic
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
+        if (WOUT) wout[u] = 0.0;
         if (!FAST && sl[u] == SLOT_NONE) continue;
         const Q4 q0 = q0b[u], q1 = q1b[u];
         const double dx = q0.a - xr, dy = q0.b - yr, dz = q0.c - zr;
@@ -266,7 +268,9 @@ __device__ __forceinline__ void density_batch(DensAcc& a, const unsigned (&sl)[N
         const double ca = ci * (qi * qi);                     // nsc:592
         a.rho += fmax(ms, 0.0) * W;                           // nsc:605
         a.rd += fmax(-ms, 0.0) * W;                           // nsc:606
-        a.n += Nw * W;                                        // nsc:607
+        const double nww = Nw * W;
+        a.n += nww;                                           // nsc:607
+        if (WOUT) wout[u] = nww;                              // nsc:626
         // nsc:615, the pair's common factor taken out of the three components: (A_j g_b + A_i g_a) / 2 = t (dx, dy, dz) with
         // t = (A_j c_b + A_i c_a) / 2 - 10 fp64 operations instead of 21, each a 4-cycle issue; a regrouping of
         // the reference's products (a few ulp per term against a bound of 1e-12 x sum|term|), the same in every variant
@@ -578,6 +582,179 @@ __global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_visc_kernel(int n, int
         }
         __syncthreads();
     }
+}
+
+// ---- pass 1 + species pass in one kernel (the step loop with a composition, hydro_update's sums) -----------------------
+// The species pass's first sweep repeats pass 1's staging and its W_ij: here pass 1 keeps every lane's weights Nw_j W_ij
+// in registers and the two composition sweeps of blob_species_kernel follow on the same slot lists - one staging and one
+// set of kernel evaluations fewer per blob (with-species step 1.65 -> see DESIGN 6.1).  Same expressions in the same
+// order as the two kernels run one after the other: bit-identical outputs.
+template <int SPEC_MAXM>
+__global__ __launch_bounds__(PASS_T, PASS_MINW) void blob_density_species_kernel(int n, int npad, int k, int nblk, int clip,
+        const int* __restrict__ nbr, const u16* __restrict__ slot16, const int* __restrict__ uniq,
+        const int* __restrict__ qorder, const RecA* __restrict__ rec, double* rho_s, double* rho, double* rhod,
+        double* nden, double* G, double* ha,
+        int S, const double* __restrict__ fun, const int* __restrict__ row_of, const double* __restrict__ m, AgbTable agb,
+        int agb_on, double* F, double* Zout, double* agb_out) {
+    extern __shared__ double2 img[];                       // 4 * BLOB_S chunks, then the slot tile
+    u16* tile = reinterpret_cast<u16*>(img + 4 * BLOB_S);
+    const int t = threadIdx.x / LPP, half = threadIdx.x & (LPP - 1);
+    const int nm = KPAD(k) / LPP;
+    for (int bi = blockIdx.x; bi < nblk; bi += gridDim.x) {
+        const int b = xcd_block(bi, nblk);
+        const int p = b * BLOB_P + t;
+        const bool live = p < n;
+        const int i = live ? qorder[p] : 0;
+        const int* uq = uniq + (size_t)b * BLOB_S;
+        stage<0>(img, nullptr, tile, rec, nullptr, 0, nullptr, 0, uq, slot16, npad, k, b);
+        const double* self = reinterpret_cast<const double*>(&rec[i]);
+        const Q4 s0 = gload4(self), s1 = gload4(self + 4);     // x y z h2 | c1 ms A Nw
+        __syncthreads();
+        double w[SPEC_MAXM];
+#pragma unroll
+        for (int mm = 0; mm < SPEC_MAXM; ++mm) w[mm] = 0.0;
+        if (live) {
+            double xr = s0.a, yr = s0.b, zr = s0.c;
+            {
+                const unsigned sl0 = tile[t];
+                if (sl0 < SLOT_OVER) { const Q4 r = lload4(img, (int)sl0, 0); xr = r.a; yr = r.b; zr = r.c; }
+                else if (sl0 == SLOT_OVER) { const int j0 = nbr[p]; xr = rec[j0].x; yr = rec[j0].y; zr = rec[j0].z; }
+            }
+            const double hi2 = s0.d, ci = -6.0 * s1.a, Ai = s1.c;
+            DensAcc a{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m0 = 0; m0 < SPEC_MAXM; m0 += NB) {
+                if (m0 < nm) {
+                    unsigned cur[NB];
+                    load_slots(cur, tile, m0, half, t);
+                    const size_t col0 = (size_t)(LPP * m0 + half) * npad + p;
+                    const bool fast = all_staged(cur);
+                    double wo[NB];
+                    if (fast && !clip) density_batch<true, false, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai, wo);
+                    else if (fast) density_batch<true, true, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai, wo);
+                    else if (!clip) density_batch<false, false, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai, wo);
+                    else density_batch<false, true, true>(a, cur, img, rec, nbr, col0, LPP * (size_t)npad, xr, yr, zr, hi2, ci, Ai, wo);
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) if (m0 + u < SPEC_MAXM) w[m0 + u] = wo[u];
+                }
+            }
+            const double s_rho = group_total(a.rho), s_rd = group_total(a.rd), s_n = group_total(a.n);
+            const double gx = group_total(a.gx), gy = group_total(a.gy), gz = group_total(a.gz);
+            if (!half) {
+                rho[i] = s_rho; rhod[i] = s_rd; nden[i] = s_n;
+                rho_s[i] = s_rho;
+                if (G) { G[3 * (size_t)i + 0] = -gx; G[3 * (size_t)i + 1] = -gy; G[3 * (size_t)i + 2] = -gz; }
+                ha[3 * (size_t)i + 0] = -gx / s_rho;                  // nsc:619
+                ha[3 * (size_t)i + 1] = -gy / s_rho;
+                ha[3 * (size_t)i + 2] = -gz / s_rho;
+            }
+        }
+        // ---- the composition sweeps of blob_species_kernel, on the weights in hand
+        double tot[16];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            __syncthreads();                                   // everybody is done with the previous image
+            {
+                int ju[NSTAGE];
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const int s = threadIdx.x + r * PASS_T;
+                    ju[r] = (s < BLOB_S) ? uq[s] : -1;
+                }
+                double2 c[NSTAGE][4];
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const int jr = ju[r] < 0 ? 0 : ju[r];
+                    const double2* g = reinterpret_cast<const double2*>(fun + (size_t)(row_of ? row_of[jr] : jr) * 16) + 4 * hh;
+                    c[r][0] = g[0]; c[r][1] = g[1]; c[r][2] = g[2]; c[r][3] = g[3];
+                }
+#pragma unroll
+                for (int r = 0; r < NSTAGE; ++r) {
+                    const int s = threadIdx.x + r * PASS_T;
+                    if (ju[r] >= 0) {
+                        img[0 * BLOB_S + s] = c[r][0]; img[1 * BLOB_S + s] = c[r][1];
+                        img[2 * BLOB_S + s] = c[r][2]; img[3 * BLOB_S + s] = c[r][3];
+                    }
+                }
+            }
+            __syncthreads();
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+#pragma unroll
+            for (int mm = 0; mm < SPEC_MAXM; ++mm) {
+                if (mm < nm) {
+                    const unsigned sl = tile[(LPP * mm + half) * BLOB_P + t];
+                    if (sl != SLOT_NONE && live) {
+                        Q4 f0, f1;
+                        if (sl < SLOT_OVER) { f0 = lload4(img, (int)sl, 0); f1 = lload4(img, (int)sl, 1); }
+                        else {
+                            const int jo = nbr[(size_t)(LPP * mm + half) * npad + p];
+                            const double* q = fun + (size_t)(row_of ? row_of[jo] : jo) * 16 + 8 * hh;
+                            f0 = gload4(q); f1 = gload4(q + 4);
+                        }
+                        const double wm = w[mm];
+                        acc[0] += wm * f0.a; acc[1] += wm * f0.b; acc[2] += wm * f0.c; acc[3] += wm * f0.d;
+                        acc[4] += wm * f1.a; acc[5] += wm * f1.b; acc[6] += wm * f1.c; acc[7] += wm * f1.d;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tot[8 * hh + q] = group_total(acc[q]);
+        }
+        if (live && !half) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < S) F[(size_t)q * n + i] = tot[q];
+        }
+        if (live && agb_on) {
+            double heavy = 0.0, all = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < S) {
+                    const double ww = tot[q] * agb.mu[q];
+                    all += ww;
+                    if (q >= 6) heavy += ww;
+                }
+            }
+            const double Z = heavy / all;                      // drv:663
+            if (!half) Zout[i] = Z;
+            const double Mi = m[i];
+            double* row = agb_out + (size_t)i * S;
+            for (int q = half; q < S; q += LPP)
+                if (!((agb.covered >> q) & 1u)) row[q] = 0.0;
+            for (int o = half; o < agb.nspl; o += LPP) {
+                double val;
+                const int target = agb_one_spline(agb, o, Mi, Z, val);
+                if (target >= 0) row[target] = val;
+            }
+        }
+        __syncthreads();                                       // the image is rewritten by the next blob
+    }
+}
+
+int sphx_blob_density_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun, const int* row_of, const double* m_sorted,
+                              double* F, double* Z, double* agb, int agb_on) {
+    const int64_t npad = sphx_pad64(n);
+    const int nblk = (int)((npad + BLOB_P - 1) / BLOB_P);
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_species_kernel<10>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(blob_density_species_kernel<16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)IMG_BYTES(64, SPHX_MAX_K)));
+        attr = true;
+    }
+#define DS_ARGS (int)n, (int)npad, k, nblk, ctx->clip_grad, ctx->nbr.as<int>(), ctx->slot16.as<u16>(), ctx->uniq.as<int>(), ctx->qorder, \
+                ctx->rec1.as<RecA>(), ctx->rho_s.as<double>(), ctx->rho.as<double>(), ctx->rhod.as<double>(), ctx->nden.as<double>(), \
+                ctx->lean_outputs ? nullptr : ctx->G.as<double>(), ctx->ha.as<double>(), S, fun, row_of, m_sorted, ctx->agb, agb_on, F, Z, agb
+    if (KPAD(k) / LPP <= 10)
+        hipLaunchKernelGGL(blob_density_species_kernel<10>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, DS_ARGS);
+    else
+        hipLaunchKernelGGL(blob_density_species_kernel<16>, dim3(sphx_blob_grid(ctx, nblk)), dim3(PASS_T), IMG_BYTES(64, k), ctx->stream, DS_ARGS);
+#undef DS_ARGS
+    HIPCHK(hipGetLastError());
+    return SPHX_OK;
 }
 
 // ---- species pass (nsc:624-627) out of LDS, + metallicity and AGB yields ---------------------------

@@ -226,6 +226,7 @@ struct sphx_ctx {
     DevBuf lbs_state[2];                   // tile words of the look-back scan (sphx_grid.hip), per launching stream
     unsigned lbs_epoch[2] = {0u, 0u};
     bool bb_direct = true;                 // the grid build's box statistics written to pinned memory by the kernel that folds them
+    bool species_fused = true;             // the step's species pass inside pass 1's kernel (SPHX_SPECIES_FUSED=0: a kernel of its own)
     bool stream_prio = true;               // main stream at the highest, side stream at the lowest device priority
     bool scan_rocprim = false;             // SPHX_SCAN_ROCPRIM=1: rocPRIM's scan instead
     DevBuf tie_list;                       // int4 {query slot, rank, index a, index b}: near ties the grouped search leaves to the list-mode launch's tie blocks
@@ -463,6 +464,8 @@ static inline double sphx_cell_feedback(sphx_ctx* ctx, int64_t n) {
     return ctx->cell_scale;
 }
 int sphx_blob_translate(sphx_ctx* ctx, int64_t n, int k);
+int sphx_blob_density_species(sphx_ctx* ctx, int64_t n, int k, int S, const double* fun, const int* row_of, const double* m_sorted,
+                              double* F, double* Z, double* agb, int agb_on);
 // device API: the main stream waits for the slot lists of the last search (built beside the record build / the h_j phase)
 int sphx_blob_join(sphx_ctx* ctx);
 int sphx_blob_density(sphx_ctx* ctx, int64_t n, int k);
