@@ -139,6 +139,7 @@ extern "C" int sphx_create(sphx_ctx** out, int device) {
     if (const char* e = env("SPHX_DEV_FORK_DEDUP")) ctx->dev_fork_dedup = atoi(e) != 0;
     if (const char* e = env("SPHX_TIE_FIX")) ctx->tie_fix = atoi(e) != 0;
     if (const char* e = env("SPHX_STREAM_PRIO")) ctx->stream_prio = atoi(e) != 0;
+    if (const char* e = env("SPHX_SCATTER_RANK")) ctx->scatter_by_rank = atoi(e) != 0;
     if (const char* e = env("SPHX_SPECIES_FUSED")) ctx->species_fused = atoi(e) != 0;
     if (const char* e = env("SPHX_BB_DIRECT")) ctx->bb_direct = atoi(e) != 0;
     if (const char* e = env("SPHX_SCAN_ROCPRIM")) ctx->scan_rocprim = atoi(e) != 0;
@@ -224,7 +225,7 @@ extern "C" void sphx_destroy(sphx_ctx* ctx) {
                      &ctx->in_j, &ctx->out_a, &ctx->out_b, &ctx->out_c, &ctx->idx64, &ctx->dist_out,
                      &ctx->nontriv, &ctx->h_api, &ctx->hsum_tmp, &ctx->grav_quad, &ctx->scal_tmp, &ctx->fail_list,
                      &ctx->agb_knots, &ctx->Zmet, &ctx->agb_dust, &ctx->need_pyr, &ctx->ds_cnt, &ctx->ds_start, &ctx->ds_ent,
-                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->badc, &ctx->tie_list, &ctx->lbs_state[0], &ctx->lbs_state[1]};
+                     &ctx->loop_side, &ctx->crowded, &ctx->fun_id, &ctx->olev_start, &ctx->olev_fill, &ctx->olev_list, &ctx->olev_key, &ctx->blob_class, &ctx->blob_split, &ctx->badc, &ctx->tie_list, &ctx->lbs_state[0], &ctx->lbs_state[1], &ctx->cell_rank};
     for (DevBuf* b : all) free_buf(*b);
     free_state(ctx->st);
     free_state(ctx->alt);

@@ -172,6 +172,7 @@ struct FusedCountArgs {
     double* fin;
     u64* ct_reset;                          // "no crossing-time vote yet" for this step's pass 2 (nullable)
     int* zero_int;                          // the search's fail-list counter, zeroed here instead of by a launch of its own (nullable)
+    int* rank;                              // (nullable) the particle's arrival number in its cell: cell_scatter then needs no atomic
 };
 __device__ __forceinline__ double nan_to_num_g(double v) {
     if (v != v) return 0.0;
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(RED_BLOCK) void grid_count_fused(FusedCountArgs a) 
         const int cz = cell_coord_g(v[2], g.zmin, g.inv_cell, g.nz - 1);
         const int c = (cz * g.ny + cy) * g.nx + cx;
         a.cell_of[i] = c;
-        atomicAdd(&a.hist[c], 1);
+        if (a.rank) a.rank[i] = atomicAdd(&a.hist[c], 1);
+        else atomicAdd(&a.hist[c], 1);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -292,7 +294,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total_out) {
 #define LBS_TILE (LBS_ITEMS * 256)
 #define LBS_MAXTILES 512           // 256 CUs x 8 workgroups of 256 threads fit at once: a quarter of that, so that four
                                    // processes sharing a device (rehearsals of several ranks on one GPU) still fit together
-__global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, const int* __restrict__ in, int* __restrict__ out,
+// ZERO: the items are put back to zero behind the read (the cell histogram: counted up by the count kernel, all zero
+// between builds)
+template <int ZERO>
+__global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, int* __restrict__ in, int* __restrict__ out,
                                                             u64* state, int* ctr, unsigned epoch, int ntiles) {
     __shared__ int s_prefix;
     const int tile = blockIdx.x;          // (every tile of a launch is resident at once - the launcher sees to it - so any order will do)
@@ -304,10 +309,14 @@ __global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, const i
         for (int q = 0; q < LBS_ITEMS; q += 4) {
             const int4 t = *reinterpret_cast<const int4*>(in + base + q);
             v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+            if (ZERO) *reinterpret_cast<int4*>(in + base + q) = make_int4(0, 0, 0, 0);
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < LBS_ITEMS; ++q) v[q] = (base + q < n_items) ? in[base + q] : 0;
+        for (int q = 0; q < LBS_ITEMS; ++q) {
+            v[q] = (base + q < n_items) ? in[base + q] : 0;
+            if (ZERO && base + q < n_items) in[base + q] = 0;
+        }
     }
 #pragma unroll
     for (int q = 0; q < LBS_ITEMS; ++q) s += v[q];
@@ -347,7 +356,9 @@ __global__ __launch_bounds__(256) void lookback_scan_kernel(int n_items, const i
         for (int q = 0; q < LBS_ITEMS; ++q) { if (base + q < n_items) out[base + q] = ex; ex += v[q]; }
     }
 }
-static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
+// zero_in: the items are put back to zero once read (*zeroed says whether that happened: rocPRIM's scan does not)
+static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n, bool zero_in = false, bool* zeroed = nullptr) {
+    if (zeroed) *zeroed = false;
     if (ctx->scan_rocprim || (((uintptr_t)in | (uintptr_t)out) & 15)) {
         size_t bytes = 0;
         HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n + 1, rocprim::plus<int>(), ctx->stream));
@@ -377,8 +388,14 @@ static int excl_scan_plus_total(sphx_ctx* ctx, const int* in, int* out, int n) {
     unsigned& ep = ctx->lbs_epoch[which];
     ep = (ep + 1u) & 0x3FFFFFFFu;
     if (ep == 0u) ep = 1u;
-    hipLaunchKernelGGL(lookback_scan_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n_items, in, out,
-                       st.as<u64>() + 2, st.as<int>(), ep, ntiles);
+    if (zero_in) {
+        hipLaunchKernelGGL(lookback_scan_kernel<1>, dim3(ntiles), dim3(256), 0, ctx->stream, n_items, const_cast<int*>(in), out,
+                           st.as<u64>() + 2, st.as<int>(), ep, ntiles);
+        if (zeroed) *zeroed = true;
+    } else {
+        hipLaunchKernelGGL(lookback_scan_kernel<0>, dim3(ntiles), dim3(256), 0, ctx->stream, n_items, const_cast<int*>(in), out,
+                           st.as<u64>() + 2, st.as<int>(), ep, ntiles);
+    }
     HIPCHK(hipGetLastError());
     return SPHX_OK;
 }
@@ -478,10 +495,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_phase3(int n, const int* in, 
 // not by anything before this kernel, so they need no launch of their own on the way (early blocks: off the kernel's tail).
 __global__ __launch_bounds__(256) void cell_scatter(int n, const int* cell_of, const int* cell_start,
                                                     int* fill, int* perm, int bb_nblocks, const double* bb_part,
-                                                    double* bb_out, double* bb_host) {
+                                                    double* bb_out, double* bb_host, const int* __restrict__ rank) {
     __shared__ double sw[4];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    if (i < n && rank) {
+        // (the count kernel kept every particle's arrival number: no second atomic per particle; the histogram was put
+        //  back to zero by the scan that read it)
+        perm[cell_start[cell_of[i]] + rank[i]] = i;
+    } else if (i < n) {
         int c = cell_of[i];
         // counts the histogram back down to zero; slots are handed out upwards (arrival order is mostly
         // the previous cell order already, which the per-cell insertion sort then finds nearly sorted)
@@ -716,6 +737,7 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
     int pb = (int)((n + 255) / 256);
     (void)bsum;
     int bb_fold_blocks = 0;
+    const int* rank_dev = nullptr;            // set: the count kernel kept the particles' arrival numbers
     const double* bb_fold_part = nullptr;
     double* bb_fold_out = nullptr;
     if (fused) {
@@ -741,6 +763,12 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         fa.partial = part; fa.ticket = ticket; fa.fin = fin;
         fa.ct_reset = ctx->scal.as<u64>() + SC_CT_BITS;      // (read by the previous step's update, long done on this stream)
         fa.zero_int = nullptr;
+        fa.rank = nullptr;
+        if (ctx->scatter_by_rank) {
+            SPHX_TRY(sphx_ensure(ctx, ctx->cell_rank, (size_t)n * sizeof(int)));
+            fa.rank = ctx->cell_rank.as<int>();
+        }
+        rank_dev = fa.rank;
         if (ctx->fail_list.p && ctx->fail_list.cap >= ((size_t)sphx_pad64(n) + 64) * sizeof(int)) {
             fa.zero_int = ctx->fail_list.as<int>() + sphx_pad64(n);          // (where sphx_knn keeps the counter for this n)
             ctx->fcount_zeroed = ctx->fail_list.p;
@@ -761,13 +789,15 @@ int sphx_build_grid(sphx_ctx* ctx, int64_t n, int k, const double* x, const doub
         hipLaunchKernelGGL(cell_count, dim3(pb), dim3(256), 0, ctx->stream, (int)n, x, y, z, g,
                            ctx->cell_of.as<int>(), fill);
     }
-    SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc));
+    bool hist_zeroed = false;
+    SPHX_TRY(excl_scan_plus_total(ctx, fill, start, nc, rank_dev != nullptr, &hist_zeroed));
     // (the statistics folded by the scatter's first blocks go straight to the pinned slot the next step's host code reads:
     //  the 104-byte copy that followed was a launch of its own on the step's stream, 5 us + its gaps)
     const bool to_host = bb_fold_part != nullptr && bb_fold_out && !ctx->capturing && pb >= BB_W && ctx->bb_direct;
     double* bb_host = to_host ? reinterpret_cast<double*>((char*)ctx->pinned + LAG_OFF + 512 * lag_cur) : nullptr;
     hipLaunchKernelGGL(cell_scatter, dim3(pb), dim3(256), 0, ctx->stream, (int)n,
-                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out, bb_host);
+                       ctx->cell_of.as<int>(), start, fill, ctx->perm.as<int>(), bb_fold_blocks, bb_fold_part, bb_fold_out, bb_host, rank_dev);
+    if (rank_dev && !hist_zeroed) HIPCHK(hipMemsetAsync(fill, 0, ((size_t)nc + 1) * sizeof(int), ctx->stream));     // (rocPRIM's scan left the counts in place)
     if (bb_fold_out && !ctx->capturing) {
         char* slot = (char*)ctx->pinned + LAG_OFF;
         if (!to_host)

@@ -227,6 +227,8 @@ struct sphx_ctx {
     unsigned lbs_epoch[2] = {0u, 0u};
     bool bb_direct = true;                 // the grid build's box statistics written to pinned memory by the kernel that folds them
     bool species_fused = true;             // the step's species pass inside pass 1's kernel (SPHX_SPECIES_FUSED=0: a kernel of its own)
+    DevBuf cell_rank;                       // the particles' arrival numbers in their cells (grid build)
+    bool scatter_by_rank = true;           // SPHX_SCATTER_RANK=0: the scatter hands out slots with an atomic of its own
     bool stream_prio = true;               // main stream at the highest, side stream at the lowest device priority
     bool scan_rocprim = false;             // SPHX_SCAN_ROCPRIM=1: rocPRIM's scan instead
     DevBuf tie_list;                       // int4 {query slot, rank, index a, index b}: near ties the grouped search leaves to the list-mode launch's tie blocks
